@@ -1,0 +1,73 @@
+"""ctypes binding of libhbr_hip.so (C ABI: include/hbr_hip.h).  Fails loudly when the library is missing."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhbr_hip.so")
+
+ROWS, PLANAR = 0, 1
+F32, BF16 = 0, 1
+MLP_PARAM_FLOATS = 14227
+
+_p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); must list every symbol declared in include/hbr_hip.h
+SIGNATURES = {
+    "hbr_version": (_i, []),
+    "hbr_strerror": (C.c_char_p, [_i]),
+    "hbr_device_ok": (_i, []),
+    "hbr_hash_encode_fwd": (_i, [_p, _p, _p, _p, _l, _l, _p, _p, _p, _f, _i, _l, _i, _p, _i, _l, _i, _p]),
+    "hbr_hash_encode_bwd": (_i, [_p, _p, _p, _p, _l, _l, _p, _i, _l, _i, _p, _p, _f, _i, _l, _i, _p, _i, _p, _l, _p]),
+    "hbr_hash_bwd_workspace_bytes": (_l, [_l, _i, _l, _i, _i]),
+    "hbr_composite_fwd": (_i, [_p, _p, _l, _p, _l, _p, _l, _l, _p, _p, _p]),
+    "hbr_composite_bwd": (_i, [_p, _p, _l, _p, _l, _p, _l, _l, _p, _p, _p, _p]),
+    "hbr_dir_encode": (_i, [_p, _l, _i, _i, _p, _p]),
+    "hbr_mlp_workspace_bytes": (_l, [_i]),
+    "hbr_mlp_fwd": (_i, [_p, _i, _l, _i, _p, _l, _l, _p, _i, _p, _p, _l, _p]),
+    "hbr_mlp_bwd": (_i, [_p, _i, _l, _i, _p, _l, _l, _p, _i, _p, _p, _p, _p, _l, _p]),
+    "hbr_mse2_loss_fwd_bwd": (_i, [_p, _p, _l, _f, _p, _p, _p]),
+    "hbr_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _l, _f, _p]),
+}
+
+_lib = None
+
+
+class HbrError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into libhbr_hip.so (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["bash", os.path.join(_HERE, "csrc", "build.sh")], capture_output=True, text=True)
+    if verbose or r.returncode:
+        print(r.stdout[-4000:], r.stderr[-4000:])
+    if r.returncode:
+        raise HbrError("building libhbr_hip.so failed")
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HbrError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU/eager fallback for this path)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the .so does not export it
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise HbrError(f"{what}: {lib().hbr_strerror(rc).decode()} (code {rc})")
+
+
+def require_gpu(t) -> None:
+    if not t.is_cuda:
+        raise HbrError("hbr_amd ops need tensors on an MI355X (cuda) device; there is no CPU fallback")

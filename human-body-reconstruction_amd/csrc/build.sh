@@ -1,0 +1,18 @@
+#!/usr/bin/env bash
+# Build libhbr_hip.so for gfx950 in-tree (cross-compiles without a GPU).
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+ROOT="$(cd "$HERE/../.." && pwd)"
+OUT="$HERE/../libhbr_hip.so"
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wno-unused-value -I"$ROOT/include" -I"$HERE")
+mkdir -p "$HERE/build"
+pids=()
+for f in c_api hash_encode composite optim mlp; do
+  if [ ! -f "$HERE/build/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/build/$f.o" ] || [ "$HERE/hbr_common.h" -nt "$HERE/build/$f.o" ] || [ "$ROOT/include/hbr_hip.h" -nt "$HERE/build/$f.o" ]; then
+    hipcc "${FLAGS[@]}" -c "$HERE/$f.hip" -o "$HERE/build/$f.o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE"/build/{c_api,hash_encode,composite,optim,mlp}.o
+echo "built $OUT"

@@ -1,0 +1,211 @@
+// K5: alpha compositing along rays (calc_color, reference helper.py:53-107, non-SDF branch) and the
+// 2*MSE loss of train_hash2.py:221.  One wavefront per ray: the S samples are swept in chunks of 64
+// lanes, the transmittance prefix is a wave-level scan (no LDS round trip for the scan itself).
+#include "hbr_common.h"
+
+namespace hbr {
+
+constexpr int kRaysPerBlock = 4;
+constexpr int kMaxChunks = 64;  // S <= 4096
+
+__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    float o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+__device__ __forceinline__ float wave_incl_scan_rev(float v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    float o = __shfl_down(v, d, 64);
+    if (lane + d < 64) v += o;
+  }
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+struct RayIn {
+  const float* t;
+  const float* rgb;
+  int64_t rgb_stride;
+  const float* sigma;
+  int64_t sigma_stride;
+  const float* dir_norm;
+  int64_t R, S;
+};
+
+// p = clamp(sigma)*delta for sample s of ray r; `live` says whether sigma's gradient flows (helper.py:76)
+__device__ __forceinline__ float sample_p(const RayIn& in, int64_t r, int64_t s, float dn, float& delta, bool& live) {
+  delta = 0.f;
+  live = false;
+  if (s >= in.S) return 0.f;
+  if (s < in.S - 1) delta = __fmul_rn(__fsub_rn(in.t[s + 1], in.t[s]), dn);  // helper.py:67,71; last delta stays 0
+  float sg = in.sigma[(r * in.S + s) * in.sigma_stride];
+  live = !(sg < -10.f);
+  if (!live) sg = -10.f;
+  return __fmul_rn(sg, delta);
+}
+
+__global__ __launch_bounds__(kRaysPerBlock * 64) void composite_fwd_kernel(RayIn in, float* __restrict__ Cr,
+                                                                           float* __restrict__ wts) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * kRaysPerBlock + (threadIdx.x >> 6);
+  if (r >= in.R) return;
+  const float dn = in.dir_norm ? in.dir_norm[r] : 1.f;
+  float carry = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+  for (int64_t base = 0; base < in.S; base += 64) {
+    const int64_t s = base + lane;
+    float delta;
+    bool live;
+    const float p = sample_p(in, r, s, dn, delta, live);
+    const float incl = wave_incl_scan(p, lane);
+    float excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 0.f;
+    const float Tr = expf(-(carry + excl));      // helper.py:93-95: exclusive transmittance, T_0 = 1
+    const float alpha = 1.f - expf(-p);          // :91
+    const float w = Tr * alpha;                  // :102
+    if (s < in.S) {
+      const float* c = in.rgb + (r * in.S + s) * in.rgb_stride;
+      c0 += w * c[0]; c1 += w * c[1]; c2 += w * c[2];
+      if (wts) wts[r * in.S + s] = w;
+    }
+    carry += __shfl(incl, 63, 64);
+  }
+  c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2);
+  if (lane == 0) {
+    Cr[r * 3 + 0] = c0; Cr[r * 3 + 1] = c1; Cr[r * 3 + 2] = c2;
+  }
+}
+
+// dL/dp_s = g_s T_s exp(-p_s) - sum_{k>s} g_k w_k,   g_s = dC . rgb_s ;  d sigma_s = live ? dL/dp_s * delta_s : 0 ;
+// d rgb_s = w_s dC.   Pass 1 records the per-chunk cumulative p; pass 2 walks the chunks backwards so the
+// suffix sum is accumulated from the far end exactly as autograd's reverse cumsum does.
+__global__ __launch_bounds__(kRaysPerBlock * 64) void composite_bwd_kernel(RayIn in, const float* __restrict__ dCr,
+                                                                           float* __restrict__ d_rgb,
+                                                                           float* __restrict__ d_sigma) {
+  __shared__ float chunk_carry[kRaysPerBlock][kMaxChunks];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int64_t r = (int64_t)blockIdx.x * kRaysPerBlock + wv;
+  if (r >= in.R) return;
+  const float dn = in.dir_norm ? in.dir_norm[r] : 1.f;
+  const float g0 = dCr[r * 3 + 0], g1 = dCr[r * 3 + 1], g2 = dCr[r * 3 + 2];
+  const int nchunks = (int)((in.S + 63) / 64);
+  float carry = 0.f;
+  for (int c = 0; c < nchunks; ++c) {
+    float delta;
+    bool live;
+    const float p = sample_p(in, r, (int64_t)c * 64 + lane, dn, delta, live);
+    if (lane == 0) chunk_carry[wv][c] = carry;
+    carry += wave_sum(p);
+  }
+  // same-wave LDS hand-off: make the stores visible before the reads below
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+  float suffix = 0.f;
+  for (int c = nchunks - 1; c >= 0; --c) {
+    const int64_t s = (int64_t)c * 64 + lane;
+    float delta;
+    bool live;
+    const float p = sample_p(in, r, s, dn, delta, live);
+    const float incl = wave_incl_scan(p, lane);
+    float excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 0.f;
+    const float Tr = expf(-(chunk_carry[wv][c] + excl));
+    const float e = expf(-p);
+    const float w = Tr * (1.f - e);
+    float g = 0.f;
+    const float* col = nullptr;
+    if (s < in.S) {
+      col = in.rgb + (r * in.S + s) * in.rgb_stride;
+      g = g0 * col[0] + g1 * col[1] + g2 * col[2];
+    }
+    const float gw = g * w;
+    const float rincl = wave_incl_scan_rev(gw, lane);
+    float rexcl = __shfl_down(rincl, 1, 64);
+    if (lane == 63) rexcl = 0.f;
+    const float dp = g * Tr * e - (suffix + rexcl);
+    if (s < in.S) {
+      d_sigma[(r * in.S + s) * in.sigma_stride] = live ? dp * delta : 0.f;
+      float* dc = d_rgb + (r * in.S + s) * in.rgb_stride;
+      dc[0] = w * g0; dc[1] = w * g1; dc[2] = w * g2;
+    }
+    suffix += __shfl(rincl, 0, 64);
+  }
+}
+
+// loss = 2*mean((Cr-gt)^2) over R*3 elements; dCr = gscale * 4*(Cr-gt)/(3R)
+__global__ __launch_bounds__(256) void mse2_kernel(const float* __restrict__ Cr, const float* __restrict__ gt, int64_t n,
+                                                   float inv_n, float gscale, float* __restrict__ loss,
+                                                   float* __restrict__ dCr) {
+  __shared__ float part[4];
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float d = Cr[i] - gt[i];
+    acc += d * d;
+    if (dCr) dCr[i] = gscale * 4.f * inv_n * d;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0 && loss) unsafeAtomicAdd(loss, 2.f * inv_n * (part[0] + part[1] + part[2] + part[3]));
+}
+
+static int check_ray_in(const RayIn& in) {
+  if (!in.t || !in.rgb || !in.sigma || in.R < 0 || in.S < 1 || in.rgb_stride < 3 || in.sigma_stride < 1) return HBR_EINVAL;
+  if (in.S > (int64_t)kMaxChunks * 64) return HBR_EUNSUPPORTED;
+  return HBR_OK;
+}
+
+}  // namespace hbr
+
+using namespace hbr;
+
+extern "C" int hbr_composite_fwd(const float* t, const float* rgb, int64_t rgb_stride, const float* sigma,
+                                 int64_t sigma_stride, const float* dir_norm, int64_t R, int64_t S, float* Cr, float* wts,
+                                 void* stream) {
+  RayIn in{t, rgb, rgb_stride, sigma, sigma_stride, dir_norm, R, S};
+  int rc = check_ray_in(in);
+  if (rc) return rc;
+  if (!Cr) return HBR_EINVAL;
+  if (R == 0) return HBR_OK;
+  const int64_t blocks = (R + kRaysPerBlock - 1) / kRaysPerBlock;
+  if (blocks > 0x7fffffffLL) return HBR_EUNSUPPORTED;
+  hipLaunchKernelGGL(composite_fwd_kernel, dim3((uint32_t)blocks), dim3(kRaysPerBlock * 64), 0, (hipStream_t)stream, in, Cr, wts);
+  HBR_RETURN_IF_LAUNCH_FAILED();
+  return HBR_OK;
+}
+
+extern "C" int hbr_composite_bwd(const float* t, const float* rgb, int64_t rgb_stride, const float* sigma,
+                                 int64_t sigma_stride, const float* dir_norm, int64_t R, int64_t S, const float* dCr,
+                                 float* d_rgb, float* d_sigma, void* stream) {
+  RayIn in{t, rgb, rgb_stride, sigma, sigma_stride, dir_norm, R, S};
+  int rc = check_ray_in(in);
+  if (rc) return rc;
+  if (!dCr || !d_rgb || !d_sigma) return HBR_EINVAL;
+  if (R == 0) return HBR_OK;
+  const int64_t blocks = (R + kRaysPerBlock - 1) / kRaysPerBlock;
+  if (blocks > 0x7fffffffLL) return HBR_EUNSUPPORTED;
+  hipLaunchKernelGGL(composite_bwd_kernel, dim3((uint32_t)blocks), dim3(kRaysPerBlock * 64), 0, (hipStream_t)stream, in, dCr, d_rgb,
+                     d_sigma);
+  HBR_RETURN_IF_LAUNCH_FAILED();
+  return HBR_OK;
+}
+
+extern "C" int hbr_mse2_loss_fwd_bwd(const float* Cr, const float* gt, int64_t R, float gscale, float* loss_out, float* dCr,
+                                     void* stream) {
+  if (!Cr || !gt || R < 0) return HBR_EINVAL;
+  if (R == 0) return HBR_OK;
+  const int64_t n = R * 3;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(mse2_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, Cr, gt, n, 1.0f / (float)n, gscale,
+                     loss_out, dCr);
+  HBR_RETURN_IF_LAUNCH_FAILED();
+  return HBR_OK;
+}

@@ -1,0 +1,313 @@
+// K1 / K2: multiresolution hash-grid encode and its gradient scatter-add, gfx950.
+//
+// Forward: one thread = one point, 64 lanes = 64 consecutive samples of a ray, so at the coarse
+// levels the lanes of a wave fall into a handful of cells and the texture path coalesces their
+// gathers.  Levels are dealt to workgroups by blockIdx % 8: workgroups are dispatched round-robin
+// over the 8 XCDs, so each XCD's private 4 MiB L2 only ever sees L/8 levels (1 MiB of fp32
+// tables at L=16, T=2^16) instead of thrashing on all 8 MiB.  Placement is a speed assumption
+// only; results do not depend on it.
+//
+// Backward: (algo 1) one float atomic per corner-feature; (algo 2) a workgroup owns one
+// 16384-row slice of one level in LDS (128 KiB), sweeps a chunk of the points, accumulates the
+// corners that fall into its slice with LDS atomics and flushes the slice once with contiguous
+// 256-B global atomics (MI355X_MICROARCH "Global float atomics": contiguous atomics run 17x the
+// one-row-per-lane rate).
+#include "hbr_common.h"
+
+namespace hbr {
+
+constexpr int kFwdThreads = 256;
+constexpr int kXcds = 8;
+
+template <int LAYOUT, int DTYPE>
+__device__ __forceinline__ void store_feat(void* y, uint32_t n, int l, uint32_t N, int64_t stride, float f0, float f1) {
+  size_t off = (LAYOUT == HBR_LAYOUT_PLANAR) ? ((size_t)l * N + n) * 2 : (size_t)n * stride + (size_t)l * 2;
+  if (DTYPE == HBR_F32) {
+    float* p = (float*)y + off;
+    if (LAYOUT == HBR_LAYOUT_PLANAR) {
+      *(float2*)p = make_float2(f0, f1);
+    } else {
+      p[0] = f0; p[1] = f1;
+    }
+  } else {
+    uint16_t* p = (uint16_t*)y + off;
+    if (LAYOUT == HBR_LAYOUT_PLANAR) {
+      *(uint32_t*)p = pack_bf16x2(f0, f1);
+    } else {
+      uint32_t v = pack_bf16x2(f0, f1);
+      p[0] = (uint16_t)v; p[1] = (uint16_t)(v >> 16);
+    }
+  }
+}
+
+template <int LAYOUT, int DTYPE>
+__device__ __forceinline__ void load_feat(const void* y, uint32_t n, int l, uint32_t N, int64_t stride, float& f0, float& f1) {
+  size_t off = (LAYOUT == HBR_LAYOUT_PLANAR) ? ((size_t)l * N + n) * 2 : (size_t)n * stride + (size_t)l * 2;
+  if (DTYPE == HBR_F32) {
+    const float* p = (const float*)y + off;
+    if (LAYOUT == HBR_LAYOUT_PLANAR) {
+      float2 v = *(const float2*)p; f0 = v.x; f1 = v.y;
+    } else {
+      f0 = p[0]; f1 = p[1];
+    }
+  } else {
+    const uint16_t* p = (const uint16_t*)y + off;
+    f0 = __uint_as_float((uint32_t)p[0] << 16);
+    f1 = __uint_as_float((uint32_t)p[1] << 16);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 forward
+// ------------------------------------------------------------------------------------------------
+template <bool POW2, int LAYOUT, int DTYPE>
+__global__ __launch_bounds__(kFwdThreads) void hash_fwd_kernel(PointSrc ps, uint32_t N, const float* __restrict__ tables,
+                                                               HashGeom g, void* __restrict__ y, int64_t y_stride,
+                                                               int levels_per_group) {
+  const int group = blockIdx.x % kXcds;
+  const uint32_t tile = blockIdx.x / kXcds;
+  const uint32_t n = tile * kFwdThreads + threadIdx.x;
+  const int l0 = group * levels_per_group;
+  if (l0 >= g.L || n >= N) return;
+  const int l1 = min(g.L, l0 + levels_per_group);
+
+  float px, py, pz, nx, ny, nz;
+  load_point(ps, n, px, py, pz);
+  normalise(g, px, py, pz, nx, ny, nz);
+
+  for (int l = l0; l < l1; ++l) {
+    Cell c = locate(nx, ny, nz, g.scale[l]);
+    uint32_t rows[8];
+    float w[8];
+    corner_rows<POW2>(g, c, rows);
+    corner_weights(c, w);
+    const float2* tab = (const float2*)tables + (size_t)l * g.T;
+    float2 fv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) fv[k] = tab[rows[k]];
+    // (fv*w).sum(-2): products rounded, then added (hash_encoding.py:144)
+    float a0 = __fmul_rn(fv[0].x, w[0]), a1 = __fmul_rn(fv[0].y, w[0]);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+      a0 = __fadd_rn(a0, __fmul_rn(fv[k].x, w[k]));
+      a1 = __fadd_rn(a1, __fmul_rn(fv[k].y, w[k]));
+    }
+    store_feat<LAYOUT, DTYPE>(y, n, l, N, y_stride, a0, a1);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 backward, algo 1: global float atomics
+// ------------------------------------------------------------------------------------------------
+template <bool POW2, int LAYOUT, int DTYPE>
+__global__ __launch_bounds__(kFwdThreads) void hash_bwd_atomic_kernel(PointSrc ps, uint32_t N, const void* __restrict__ dy,
+                                                                      int64_t dy_stride, HashGeom g,
+                                                                      float* __restrict__ dtables, int levels_per_group) {
+  const int group = blockIdx.x % kXcds;
+  const uint32_t tile = blockIdx.x / kXcds;
+  const uint32_t n = tile * kFwdThreads + threadIdx.x;
+  const int l0 = group * levels_per_group;
+  if (l0 >= g.L || n >= N) return;
+  const int l1 = min(g.L, l0 + levels_per_group);
+
+  float px, py, pz, nx, ny, nz;
+  load_point(ps, n, px, py, pz);
+  normalise(g, px, py, pz, nx, ny, nz);
+
+  for (int l = l0; l < l1; ++l) {
+    float d0, d1;
+    load_feat<LAYOUT, DTYPE>(dy, n, l, N, dy_stride, d0, d1);
+    Cell c = locate(nx, ny, nz, g.scale[l]);
+    uint32_t rows[8];
+    float w[8];
+    corner_rows<POW2>(g, c, rows);
+    corner_weights(c, w);
+    float* tab = dtables + (size_t)l * g.T * 2;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      unsafeAtomicAdd(tab + (size_t)rows[k] * 2 + 0, __fmul_rn(w[k], d0));
+      unsafeAtomicAdd(tab + (size_t)rows[k] * 2 + 1, __fmul_rn(w[k], d1));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 backward, algo 2: LDS-resident table slice per workgroup
+// ------------------------------------------------------------------------------------------------
+constexpr int kSliceLog2 = 14;                 // 16384 rows * 2 floats * 4 B = 128 KiB of the CU's 160 KiB LDS
+constexpr int kSliceRows = 1 << kSliceLog2;
+constexpr int kLdsBwdThreads = 1024;
+
+template <bool POW2, int LAYOUT, int DTYPE>
+__global__ __launch_bounds__(kLdsBwdThreads) void hash_bwd_lds_kernel(PointSrc ps, uint32_t N, const void* __restrict__ dy,
+                                                                      int64_t dy_stride, HashGeom g,
+                                                                      float* __restrict__ dtables, int slices_per_level,
+                                                                      int chunks) {
+  extern __shared__ float acc[];  // [kSliceRows][2]
+  // block -> (level, slice, chunk); chunk varies fastest so the blocks of one (level, slice) start together
+  const uint32_t b = blockIdx.x;
+  const uint32_t chunk = b % chunks;
+  const uint32_t ls = b / chunks;
+  const uint32_t slice = ls % slices_per_level;
+  const int l = ls / slices_per_level;
+
+  for (int i = threadIdx.x; i < kSliceRows * 2; i += kLdsBwdThreads) acc[i] = 0.f;
+  __syncthreads();
+
+  const uint32_t row_lo = slice << kSliceLog2;
+  const uint32_t per = (N + chunks - 1) / chunks;
+  const uint32_t n_begin = chunk * per;
+  const uint32_t n_end = min(N, n_begin + per);
+  const float scale = g.scale[l];
+
+  for (uint32_t n = n_begin + threadIdx.x; n < n_end; n += kLdsBwdThreads) {
+    float px, py, pz, nx, ny, nz, d0, d1;
+    load_point(ps, n, px, py, pz);
+    load_feat<LAYOUT, DTYPE>(dy, n, l, N, dy_stride, d0, d1);
+    normalise(g, px, py, pz, nx, ny, nz);
+    Cell c = locate(nx, ny, nz, scale);
+    uint32_t rows[8];
+    float w[8];
+    corner_rows<POW2>(g, c, rows);
+    corner_weights(c, w);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      uint32_t rel = rows[k] - row_lo;  // wraps to a huge value when the row is below the slice
+      if (rel < (uint32_t)kSliceRows) {
+        atomicAdd(&acc[rel * 2 + 0], __fmul_rn(w[k], d0));
+        atomicAdd(&acc[rel * 2 + 1], __fmul_rn(w[k], d1));
+      }
+    }
+  }
+  __syncthreads();
+
+  // flush: contiguous 256-B wave-instructions of float atomics; skip exact zeros (untouched rows)
+  const int64_t rows_here = min((int64_t)kSliceRows, g.T - (int64_t)row_lo);
+  float* out = dtables + ((size_t)l * g.T + row_lo) * 2;
+  for (int64_t i = threadIdx.x; i < rows_here * 2; i += kLdsBwdThreads) {
+    float v = acc[i];
+    if (v != 0.f) unsafeAtomicAdd(out + i, v);
+  }
+}
+
+template <bool POW2, int LAYOUT>
+static int launch_fwd_dtype(int dtype, dim3 grid, hipStream_t st, PointSrc ps, uint32_t N, const float* tables,
+                            const HashGeom& g, void* y, int64_t stride, int lpg) {
+  if (dtype == HBR_F32)
+    hipLaunchKernelGGL((hash_fwd_kernel<POW2, LAYOUT, HBR_F32>), grid, dim3(kFwdThreads), 0, st, ps, N, tables, g, y, stride, lpg);
+  else
+    hipLaunchKernelGGL((hash_fwd_kernel<POW2, LAYOUT, HBR_BF16>), grid, dim3(kFwdThreads), 0, st, ps, N, tables, g, y, stride, lpg);
+  return HBR_OK;
+}
+
+template <bool POW2, int LAYOUT, int DTYPE>
+static void launch_bwd(int algo, hipStream_t st, PointSrc ps, uint32_t N, const void* dy, int64_t stride, const HashGeom& g,
+                       float* dtables) {
+  if (algo == 1) {
+    const int lpg = (g.L + kXcds - 1) / kXcds;
+    const uint32_t tiles = (N + kFwdThreads - 1) / kFwdThreads;
+    hipLaunchKernelGGL((hash_bwd_atomic_kernel<POW2, LAYOUT, DTYPE>), dim3(tiles * kXcds), dim3(kFwdThreads), 0, st, ps, N, dy,
+                       stride, g, dtables, lpg);
+  } else {
+    const int spl = (int)((g.T + kSliceRows - 1) / kSliceRows);
+    // enough chunks to give every CU a block (256 CUs), at most one chunk per 1024-point stripe
+    int chunks = (512 + g.L * spl - 1) / (g.L * spl);
+    int max_chunks = (int)((N + kLdsBwdThreads - 1) / kLdsBwdThreads);
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks < 1) chunks = 1;
+    static bool attr_set[2][2][2] = {};
+    auto kern = hash_bwd_lds_kernel<POW2, LAYOUT, DTYPE>;
+    if (!attr_set[POW2][LAYOUT][DTYPE]) {
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kSliceRows * 2 * sizeof(float));
+      attr_set[POW2][LAYOUT][DTYPE] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((uint32_t)(g.L * spl * chunks)), dim3(kLdsBwdThreads), kSliceRows * 2 * sizeof(float), st, ps, N,
+                       dy, stride, g, dtables, spl, chunks);
+  }
+}
+
+static int check_points(const float* x, const float* o, const float* d, const float* t, int64_t R, int64_t S, PointSrc& ps,
+                        uint32_t& N) {
+  if (R < 0 || S < 1) return HBR_EINVAL;
+  if (R * S > 0x7fffffffLL) return HBR_EUNSUPPORTED;
+  N = (uint32_t)(R * S);
+  if (x) {
+    ps = PointSrc{x, nullptr, nullptr, nullptr, (uint32_t)S};
+  } else {
+    if (!o || !d || !t) return HBR_EINVAL;
+    ps = PointSrc{nullptr, o, d, t, (uint32_t)S};
+  }
+  return HBR_OK;
+}
+
+}  // namespace hbr
+
+using namespace hbr;
+
+extern "C" int hbr_hash_encode_fwd(const float* x, const float* rays_o, const float* rays_d, const float* t, int64_t R,
+                                   int64_t S, const float* tables, const float* scales_host, const float* mu_host,
+                                   float sigma, int L, int64_t T, int F, void* y, int layout, int64_t y_stride, int y_dtype,
+                                   void* stream) {
+  if (!tables || !y) return HBR_EINVAL;
+  if (F != 2) return HBR_EUNSUPPORTED;
+  if (layout != HBR_LAYOUT_ROWS && layout != HBR_LAYOUT_PLANAR) return HBR_EINVAL;
+  if (y_dtype != HBR_F32 && y_dtype != HBR_BF16) return HBR_EINVAL;
+  if (layout == HBR_LAYOUT_ROWS && y_stride < (int64_t)L * F) return HBR_EINVAL;
+  HashGeom g;
+  int rc = fill_geom(g, scales_host, mu_host, sigma, L, T);
+  if (rc) return rc;
+  PointSrc ps;
+  uint32_t N;
+  rc = check_points(x, rays_o, rays_d, t, R, S, ps, N);
+  if (rc) return rc;
+  if (N == 0) return HBR_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int lpg = (L + kXcds - 1) / kXcds;
+  const uint32_t tiles = (N + kFwdThreads - 1) / kFwdThreads;
+  dim3 grid(tiles * kXcds);
+  if (g.pow2) {
+    if (layout == HBR_LAYOUT_PLANAR) launch_fwd_dtype<true, HBR_LAYOUT_PLANAR>(y_dtype, grid, st, ps, N, tables, g, y, y_stride, lpg);
+    else launch_fwd_dtype<true, HBR_LAYOUT_ROWS>(y_dtype, grid, st, ps, N, tables, g, y, y_stride, lpg);
+  } else {
+    if (layout == HBR_LAYOUT_PLANAR) launch_fwd_dtype<false, HBR_LAYOUT_PLANAR>(y_dtype, grid, st, ps, N, tables, g, y, y_stride, lpg);
+    else launch_fwd_dtype<false, HBR_LAYOUT_ROWS>(y_dtype, grid, st, ps, N, tables, g, y, y_stride, lpg);
+  }
+  HBR_RETURN_IF_LAUNCH_FAILED();
+  return HBR_OK;
+}
+
+extern "C" int64_t hbr_hash_bwd_workspace_bytes(int64_t, int, int64_t, int, int) { return 0; }
+
+extern "C" int hbr_hash_encode_bwd(const float* x, const float* rays_o, const float* rays_d, const float* t, int64_t R,
+                                   int64_t S, const void* dy, int layout, int64_t dy_stride, int dy_dtype,
+                                   const float* scales_host, const float* mu_host, float sigma, int L, int64_t T, int F,
+                                   float* dtables, int algo, void*, int64_t, void* stream) {
+  if (!dy || !dtables) return HBR_EINVAL;
+  if (F != 2) return HBR_EUNSUPPORTED;
+  if (layout != HBR_LAYOUT_ROWS && layout != HBR_LAYOUT_PLANAR) return HBR_EINVAL;
+  if (dy_dtype != HBR_F32 && dy_dtype != HBR_BF16) return HBR_EINVAL;
+  if (layout == HBR_LAYOUT_ROWS && dy_stride < (int64_t)L * F) return HBR_EINVAL;
+  if (algo < 0 || algo > 2) return HBR_EINVAL;
+  HashGeom g;
+  int rc = fill_geom(g, scales_host, mu_host, sigma, L, T);
+  if (rc) return rc;
+  PointSrc ps;
+  uint32_t N;
+  rc = check_points(x, rays_o, rays_d, t, R, S, ps, N);
+  if (rc) return rc;
+  if (N == 0) return HBR_OK;
+  // auto: the LDS-slice kernel wins once there are enough points to amortise its fixed 128 KiB flush per block
+  if (algo == 0) algo = (N >= 65536u) ? 2 : 1;
+  hipStream_t st = (hipStream_t)stream;
+#define HBR_BWD(P, LY, DT) launch_bwd<P, LY, DT>(algo, st, ps, N, dy, dy_stride, g, dtables)
+  if (g.pow2) {
+    if (layout == HBR_LAYOUT_PLANAR) { if (dy_dtype == HBR_F32) HBR_BWD(true, HBR_LAYOUT_PLANAR, HBR_F32); else HBR_BWD(true, HBR_LAYOUT_PLANAR, HBR_BF16); }
+    else { if (dy_dtype == HBR_F32) HBR_BWD(true, HBR_LAYOUT_ROWS, HBR_F32); else HBR_BWD(true, HBR_LAYOUT_ROWS, HBR_BF16); }
+  } else {
+    if (layout == HBR_LAYOUT_PLANAR) { if (dy_dtype == HBR_F32) HBR_BWD(false, HBR_LAYOUT_PLANAR, HBR_F32); else HBR_BWD(false, HBR_LAYOUT_PLANAR, HBR_BF16); }
+    else { if (dy_dtype == HBR_F32) HBR_BWD(false, HBR_LAYOUT_ROWS, HBR_F32); else HBR_BWD(false, HBR_LAYOUT_ROWS, HBR_BF16); }
+  }
+#undef HBR_BWD
+  HBR_RETURN_IF_LAUNCH_FAILED();
+  return HBR_OK;
+}

@@ -1,0 +1,782 @@
+// K3 / K4: fused density + colour MLP of the hash-NeRF (reference test_hash.py:20-72, the instance
+// built at train_hash2.py:127: 32->64->64->16, [15 geo + 24 dir-PE]->64->64->3), forward and backward,
+// on the gfx950 matrix cores.
+//
+// Layout idea ("orientation 1"): every GEMM is computed transposed, Z^T[out][point] = W[out][in] * X^T[in][point],
+// with v_mfma_f32_32x32x16_bf16 (or the exact-f32 v_mfma_f32_32x32x2_f32).  The 32x32 result keeps the POINT on
+// the lane and 16 output features in the lane's registers, which is exactly the B-operand shape of the next
+// layer's MFMA (cdna_hip_programming.md section 3, "An accumulator tile as the next MFMA's operand"), so the whole
+// 6-layer chain - and the data-gradient chain back - runs in registers with no LDS traffic for activations.
+// One wave owns 32 points at a time.
+//
+// Weight gradients sum over points, i.e. need the point on the K axis.  Instead of staging activations through
+// LDS, each needed tensor is transposed by one more MFMA against an identity operand (exact: every product is
+// x*1 or x*0), which yields "orientation 2" tiles [point in registers][feature on lane] that feed the
+// dW^T = X^T_tile * dZ_tile MFMAs directly.  dW tiles are accumulated in a per-workgroup fp32 LDS image with
+// ds_add_f32 and flushed once per workgroup with contiguous global float atomics.
+//
+// Weights are re-packed into MFMA-fragment order by a tiny kernel on every call (parameters are updated in
+// place by the optimiser between calls; nothing is cached across calls), then held in LDS.
+#include "hbr_common.h"
+
+namespace hbr {
+namespace mlp {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// flat parameter block (hbr_hip.h): offsets of the six nn.Linear layers
+constexpr int OFF_S0W = 0, OFF_S0B = 2048, OFF_S2W = 2112, OFF_S2B = 6208, OFF_S4W = 6272, OFF_S4B = 7296;
+constexpr int OFF_C0W = 7312, OFF_C0B = 9808, OFF_C2W = 9872, OFF_C2B = 13968, OFF_C4W = 14032, OFF_C4B = 14224;
+static_assert(OFF_C4B + 3 == HBR_MLP_PARAM_FLOATS, "parameter block size");
+
+// layer ids
+enum { L1 = 0, L2 = 1, L3 = 2, C1 = 3, C2 = 4, C3 = 5, NLAYER = 6 };
+
+// Logical, zero-padded weight of layer `l`: row = output feature, col = input slot.
+//  L3: 16 real rows (row 0 density, rows 1..15 geo features).
+//  C1: input slots are the L3 tile's rows: slot 0 = density (weight 0), slots 1..15 = geo (reference cat order,
+//      test_hash.py:66), slots 16..39 = the 24 dir-PE values, so col0.weight column = slot-1.
+//  C3: 3 real rows (r,g,b).
+__device__ __host__ inline int wlog_offset(int l, int row, int col) {
+  switch (l) {
+    case L1: return (row < 64 && col < 32) ? OFF_S0W + row * 32 + col : -1;
+    case L2: return (row < 64 && col < 64) ? OFF_S2W + row * 64 + col : -1;
+    case L3: return (row < 16 && col < 64) ? OFF_S4W + row * 64 + col : -1;
+    case C1: return (row < 64 && col >= 1 && col < 40) ? OFF_C0W + row * 39 + (col - 1) : -1;
+    case C2: return (row < 64 && col < 64) ? OFF_C2W + row * 64 + col : -1;
+    case C3: return (row < 3 && col < 64) ? OFF_C4W + row * 64 + col : -1;
+  }
+  return -1;
+}
+__device__ __host__ inline int blog_offset(int l, int row) {
+  switch (l) {
+    case L1: return row < 64 ? OFF_S0B + row : -1;
+    case L2: return row < 64 ? OFF_S2B + row : -1;
+    case L3: return row < 16 ? OFF_S4B + row : -1;
+    case C1: return row < 64 ? OFF_C0B + row : -1;
+    case C2: return row < 64 ? OFF_C2B + row : -1;
+    case C3: return row < 3 ? OFF_C4B + row : -1;
+  }
+  return -1;
+}
+
+// row of a 32x32 accumulator tile held in register q of a lane in half h (cdna_hip_programming.md section 3)
+__device__ __host__ constexpr int acc_row(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
+
+// ------------------------------------------------------------------------------------------------
+// precision policies
+// ------------------------------------------------------------------------------------------------
+struct PBf16 {
+  using frag = bf16x8;
+  static constexpr int S32 = 2, S16 = 1, S8 = 1;  // k-steps covering 32 / 16 / 8 rows of a tile
+  static constexpr int ELEMS = 8;
+  // logical row (within its 32-row tile) that element j of the step-s fragment of a lane in half h stands for
+  __device__ __host__ static constexpr int rho(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
+  __device__ static __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+  __device__ static __forceinline__ frag from_acc(const f32x16& acc, int s) {
+    frag f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (__bf16)acc[8 * s + j];
+    return f;
+  }
+  __device__ static __forceinline__ frag zero() {
+    frag f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (__bf16)0.f;
+    return f;
+  }
+  __device__ static __forceinline__ frag ident(int s, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    frag f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (__bf16)((r == rho(s, h, j)) ? 1.f : 0.f);
+    return f;
+  }
+  // the three k-steps of the colour net's first layer: L3 tile rows 0..15, PE 0..15, PE 16..23
+  __device__ static __forceinline__ void cin(const f32x16& acc3, float4 peA, float4 peB, float4 peC, frag (&out)[3]) {
+    out[0] = from_acc(acc3, 0);
+    out[1][0] = (__bf16)peA.x; out[1][1] = (__bf16)peA.y; out[1][2] = (__bf16)peA.z; out[1][3] = (__bf16)peA.w;
+    out[1][4] = (__bf16)peB.x; out[1][5] = (__bf16)peB.y; out[1][6] = (__bf16)peB.z; out[1][7] = (__bf16)peB.w;
+    out[2] = zero();
+    out[2][0] = (__bf16)peC.x; out[2][1] = (__bf16)peC.y; out[2][2] = (__bf16)peC.z; out[2][3] = (__bf16)peC.w;
+  }
+  // features of one point for step s: element j <- feature rho(s,h,j); v[4] are the (f0,f1) pairs of levels
+  // 8s+2h, 8s+2h+1, 8s+4+2h, 8s+4+2h+1
+  __device__ static __forceinline__ frag feat_frag(const float2 (&v)[4]) {
+    frag f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { f[2 * k] = (__bf16)v[k].x; f[2 * k + 1] = (__bf16)v[k].y; }
+    return f;
+  }
+};
+
+struct PF32 {
+  using frag = float;
+  static constexpr int S32 = 16, S16 = 8, S8 = 4;
+  static constexpr int ELEMS = 1;
+  __device__ __host__ static constexpr int rho(int s, int h, int) { return acc_row(s, h); }
+  __device__ static __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+  __device__ static __forceinline__ frag from_acc(const f32x16& acc, int s) { return acc[s]; }
+  __device__ static __forceinline__ frag zero() { return 0.f; }
+  __device__ static __forceinline__ frag ident(int s, int lane) { return ((lane & 31) == acc_row(s, lane >> 5)) ? 1.f : 0.f; }
+  __device__ static __forceinline__ void cin(const f32x16& acc3, float4 peA, float4 peB, float4 peC, frag (&out)[20]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) out[q] = acc3[q];
+    out[8] = peA.x; out[9] = peA.y; out[10] = peA.z; out[11] = peA.w;
+    out[12] = peB.x; out[13] = peB.y; out[14] = peB.z; out[15] = peB.w;
+    out[16] = peC.x; out[17] = peC.y; out[18] = peC.z; out[19] = peC.w;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// fragment-image tables (shared by the pack kernel and the compute kernels)
+// ------------------------------------------------------------------------------------------------
+template <class P>
+struct Tab {
+  // forward: output-feature tiles and k-steps (input slots) per layer
+  __device__ __host__ static constexpr int f_out_tiles(int l) { return (l == L3 || l == C3) ? 1 : 2; }
+  __device__ __host__ static constexpr int f_ksteps(int l) { return l == L1 ? P::S32 : (l == C1 ? P::S32 + P::S8 : 2 * P::S32); }
+  __device__ __host__ static constexpr int f_base(int l) {
+    int b = 0;
+    for (int i = 0; i < l; ++i) b += f_out_tiles(i) * f_ksteps(i);
+    return b;
+  }
+  static constexpr int F_FRAGS = f_base(NLAYER);
+  // backward (data gradient): output = input-feature tiles, k-steps over the layer's output features
+  __device__ __host__ static constexpr int b_out_tiles(int l) { return (l == L1 || l == C1) ? 1 : 2; }
+  __device__ __host__ static constexpr int b_ksteps(int l) { return l == L3 ? P::S16 : (l == C3 ? P::S8 : 2 * P::S32); }
+  __device__ __host__ static constexpr int b_base(int l) {
+    int b = F_FRAGS;
+    for (int i = 0; i < l; ++i) b += b_out_tiles(i) * b_ksteps(i);
+    return b;
+  }
+  static constexpr int ALL_FRAGS = b_base(NLAYER);
+  static constexpr int FRAG_BYTES = (int)sizeof(typename P::frag) * 64;
+  static constexpr int BIAS_OFF_F = F_FRAGS * FRAG_BYTES;      // when only the forward image is staged
+  static constexpr int BIAS_OFF_ALL = ALL_FRAGS * FRAG_BYTES;  // in the full image
+  static constexpr int BIAS_BYTES = NLAYER * 64 * 4;
+  static constexpr int IMG_BYTES = BIAS_OFF_ALL + BIAS_BYTES;
+};
+
+// global image: [ALL_FRAGS][64 lanes] fragments, then [6][64] padded biases
+template <class P>
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ params, char* __restrict__ img) {
+  using T = Tab<P>;
+  const int total = T::ALL_FRAGS * 64;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total + NLAYER * 64; e += gridDim.x * 256) {
+    if (e >= total) {  // biases
+      const int b = e - total, l = b / 64, row = b % 64;
+      const int off = blog_offset(l, row);
+      ((float*)(img + T::BIAS_OFF_ALL))[b] = off >= 0 ? params[off] : 0.f;
+      continue;
+    }
+    const int fid = e / 64, lane = e % 64, r = lane & 31, h = lane >> 5;
+    const bool fwd = fid < T::F_FRAGS;
+    int l = 0, base = fwd ? 0 : T::F_FRAGS;
+    for (;; ++l) {
+      const int cnt = fwd ? T::f_out_tiles(l) * T::f_ksteps(l) : T::b_out_tiles(l) * T::b_ksteps(l);
+      if (fid < base + cnt) break;
+      base += cnt;
+    }
+    const int nk = fwd ? T::f_ksteps(l) : T::b_ksteps(l);
+    const int m = (fid - base) / nk, ks = (fid - base) % nk;
+    const int n = ks / P::S32, s = ks % P::S32;
+    typename P::frag f;
+    float vals[8];
+#pragma unroll
+    for (int j = 0; j < P::ELEMS; ++j) {
+      const int kk = 32 * n + P::rho(s, h, j);
+      const int off = fwd ? wlog_offset(l, 32 * m + r, kk) : wlog_offset(l, kk, 32 * m + r);
+      vals[j] = off >= 0 ? params[off] : 0.f;
+    }
+    if constexpr (P::ELEMS == 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = (__bf16)vals[j];
+    } else {
+      f = vals[0];
+    }
+    ((typename P::frag*)img)[e] = f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// device building blocks
+// ------------------------------------------------------------------------------------------------
+template <class P>
+__device__ __forceinline__ typename P::frag ldw(const char* img, int fid, int lane) {
+  return ((const typename P::frag*)img)[fid * 64 + lane];
+}
+
+// acc[m] = bias ; acc[m] += sum_ks W_frag(m,ks) * x[ks]      (orientation 1)
+template <class P, int NOUT, int NK, bool BIAS>
+__device__ __forceinline__ void dense(const char* img, int fbase, const float* bias, int lane, const typename P::frag (&x)[NK],
+                                      f32x16 (&acc)[NOUT]) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int m = 0; m < NOUT; ++m) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (BIAS) b = *(const float4*)(bias + 32 * m + 8 * g + 4 * h);
+      acc[m][4 * g + 0] = b.x; acc[m][4 * g + 1] = b.y; acc[m][4 * g + 2] = b.z; acc[m][4 * g + 3] = b.w;
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < NOUT; ++m) {
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) acc[m] = P::mfma(ldw<P>(img, fbase + m * NK + ks, lane), x[ks], acc[m]);
+  }
+}
+
+template <class P, int NT>
+__device__ __forceinline__ void relu_frags(f32x16 (&acc)[NT], uint32_t& mask, typename P::frag (&out)[NT * P::S32]) {
+  mask = 0;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const bool pos = acc[t][q] > 0.f;
+      mask |= pos ? (1u << (t * 16 + q)) : 0u;
+      acc[t][q] = pos ? acc[t][q] : 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < P::S32; ++s) out[t * P::S32 + s] = P::from_acc(acc[t], s);
+  }
+}
+
+template <class P, int NT>
+__device__ __forceinline__ void mask_frags(f32x16 (&acc)[NT], uint32_t mask, typename P::frag (&out)[NT * P::S32]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[t][q] = ((mask >> (t * 16 + q)) & 1u) ? acc[t][q] : 0.f;
+#pragma unroll
+    for (int s = 0; s < P::S32; ++s) out[t * P::S32 + s] = P::from_acc(acc[t], s);
+  }
+}
+
+struct FeatSrc {
+  const void* p;
+  int64_t stride;  // rows layout
+  uint32_t N;
+};
+
+// one point's 32 features -> the S32 fragments of the single input tile
+template <class P, int LAYOUT, int DT>
+__device__ __forceinline__ void load_feat_frags(const FeatSrc& fs, uint32_t n, bool valid, int h, typename P::frag (&x)[P::S32]) {
+  // feature pair (2l, 2l+1) of level l; a lane in half h owns levels {2h,2h+1, 4+2h,4+2h+1, 8+.., 12+..}
+  float2 v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int lvl = 4 * (k >> 1) + 2 * h + (k & 1);
+    v[k] = make_float2(0.f, 0.f);
+    if (valid) {
+      if (LAYOUT == HBR_LAYOUT_PLANAR) {
+        if (DT == HBR_F32) v[k] = ((const float2*)fs.p)[(size_t)lvl * fs.N + n];
+        else { uint32_t u = ((const uint32_t*)fs.p)[(size_t)lvl * fs.N + n]; v[k] = make_float2(bf16_lo(u), bf16_hi(u)); }
+      } else {
+        if (DT == HBR_F32) v[k] = *(const float2*)((const float*)fs.p + (size_t)n * fs.stride + 2 * lvl);
+        else { uint32_t u = *(const uint32_t*)((const uint16_t*)fs.p + (size_t)n * fs.stride + 2 * lvl); v[k] = make_float2(bf16_lo(u), bf16_hi(u)); }
+      }
+    }
+  }
+  if constexpr (P::ELEMS == 8) {
+    // step s, element j <-> feature 16s + 8(j>>2) + 4h + (j&3)  == levels 8s+2h, 8s+2h+1, 8s+4+2h, 8s+4+2h+1
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const float2 w[4] = {v[4 * s + 0], v[4 * s + 1], v[4 * s + 2], v[4 * s + 3]};
+      x[s] = PBf16::feat_frag(w);
+    }
+  } else {
+    // step q <-> feature (q&3) + 8(q>>2) + 4h : level 4(q>>2) + 2h + ((q&3)>>1), component q&1
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float2 p = v[2 * (q >> 2) + ((q & 3) >> 1)];
+      x[q] = (q & 1) ? p.y : p.x;
+    }
+  }
+}
+
+// everything the backward pass needs from the recomputed forward of one 32-point tile
+template <class P>
+struct Saved {
+  typename P::frag x0[P::S32];
+  typename P::frag h1[2 * P::S32];
+  typename P::frag h2[2 * P::S32];
+  typename P::frag cin[P::S32 + P::S8];
+  typename P::frag c1[2 * P::S32];
+  typename P::frag c2[2 * P::S32];
+  uint32_t m1, m2, mc1, mc2;
+  float s0;            // raw density (row 0 of the L3 tile; meaningful on h == 0 lanes)
+  float raw[3];        // raw rgb (rows 0..2 of the C3 tile; h == 0 lanes)
+};
+
+struct PeSrc {
+  const float* pe;  // [G,24] encoded view directions
+  uint32_t group;   // points per row of pe (S for per-ray directions, 1 for per-point)
+};
+
+template <class P, int LAYOUT, int DT>
+__device__ __forceinline__ void forward_tile(const char* img, const float* bias, const FeatSrc& fs, const PeSrc& ps, uint32_t n,
+                                             bool valid, int lane, Saved<P>& sv) {
+  using T = Tab<P>;
+  const int h = lane >> 5;
+  load_feat_frags<P, LAYOUT, DT>(fs, n, valid, h, sv.x0);
+  float4 peA = make_float4(0, 0, 0, 0), peB = peA, peC = peA;
+  if (valid) {
+    const float* pr = ps.pe + (size_t)(n / ps.group) * 24;
+    peA = *(const float4*)(pr + 4 * h);
+    peB = *(const float4*)(pr + 8 + 4 * h);
+    peC = *(const float4*)(pr + 16 + 4 * h);
+  }
+  {
+    f32x16 a[2];
+    dense<P, 2, P::S32, true>(img, T::f_base(L1), bias + 64 * L1, lane, sv.x0, a);
+    relu_frags<P, 2>(a, sv.m1, sv.h1);
+  }
+  {
+    f32x16 a[2];
+    dense<P, 2, 2 * P::S32, true>(img, T::f_base(L2), bias + 64 * L2, lane, sv.h1, a);
+    relu_frags<P, 2>(a, sv.m2, sv.h2);
+  }
+  {
+    f32x16 a[1];
+    dense<P, 1, 2 * P::S32, true>(img, T::f_base(L3), bias + 64 * L3, lane, sv.h2, a);
+    sv.s0 = a[0][0];
+    P::cin(a[0], peA, peB, peC, sv.cin);
+  }
+  {
+    f32x16 a[2];
+    dense<P, 2, P::S32 + P::S8, true>(img, T::f_base(C1), bias + 64 * C1, lane, sv.cin, a);
+    relu_frags<P, 2>(a, sv.mc1, sv.c1);
+  }
+  {
+    f32x16 a[2];
+    dense<P, 2, 2 * P::S32, true>(img, T::f_base(C2), bias + 64 * C2, lane, sv.c1, a);
+    relu_frags<P, 2>(a, sv.mc2, sv.c2);
+  }
+  {
+    f32x16 a[1];
+    dense<P, 1, 2 * P::S32, true>(img, T::f_base(C3), bias + 64 * C3, lane, sv.c2, a);
+    sv.raw[0] = a[0][0]; sv.raw[1] = a[0][1]; sv.raw[2] = a[0][2];
+  }
+}
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }          // test_hash.py:38,67
+__device__ __forceinline__ float lrelu(float x) { return x > 0.f ? x : 0.01f * x; }          // test_hash.py:39,62
+
+// cooperative copy global image -> LDS (16-byte vectors)
+__device__ __forceinline__ void stage_image(char* dst, const char* src, int bytes) {
+  for (int i = threadIdx.x * 16; i < bytes; i += blockDim.x * 16) *(float4*)(dst + i) = *(const float4*)(src + i);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward kernel
+// ------------------------------------------------------------------------------------------------
+constexpr int kFwdWaves = 4;
+
+template <class P, int LAYOUT, int DT>
+__global__ __launch_bounds__(kFwdWaves * 64) void mlp_fwd_kernel(const char* __restrict__ gimg, FeatSrc fs, PeSrc ps,
+                                                                 float* __restrict__ out) {
+  using T = Tab<P>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // forward fragments, then the bias block right behind them
+  stage_image(smem, gimg, T::BIAS_OFF_F);
+  stage_image(smem + T::BIAS_OFF_F, gimg + T::BIAS_OFF_ALL, T::BIAS_BYTES);
+  __syncthreads();
+  const float* bias = (const float*)(smem + T::BIAS_OFF_F);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t ntiles = (fs.N + 31) / 32;
+  for (uint32_t tile = blockIdx.x * kFwdWaves + wv; tile < ntiles; tile += gridDim.x * kFwdWaves) {
+    const uint32_t n = tile * 32 + (lane & 31);
+    const bool valid = n < fs.N;
+    Saved<P> sv;
+    forward_tile<P, LAYOUT, DT>(smem, bias, fs, ps, n, valid, lane, sv);
+    if (valid && lane < 32) {
+      ((float4*)out)[n] = make_float4(elu1(sv.raw[0]), elu1(sv.raw[1]), elu1(sv.raw[2]), lrelu(sv.s0));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward kernel
+// ------------------------------------------------------------------------------------------------
+constexpr int kDwTiles = 18;  // L1:2 L2:4 L3:2 C1:4 C2:4 C3:2
+__device__ __host__ constexpr int dw_tile_base(int l) {
+  constexpr int b[NLAYER] = {0, 2, 6, 8, 12, 16};
+  return b[l];
+}
+constexpr int kDwBytes = kDwTiles * 16 * 64 * 4;
+constexpr int kDbBytes = NLAYER * 64 * 4;
+
+// orientation-2 fragments of a tensor given its orientation-1 fragments: xt[tile][s'] (k = points)
+template <class P, int NT, int NK>
+__device__ __forceinline__ void transpose_frags(const typename P::frag (&x)[NK], int lane, typename P::frag (&xt)[NT][P::S32]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+    for (int s = 0; s < P::S32; ++s) {
+      if (t * P::S32 + s < NK) acc = P::mfma(x[t * P::S32 + s], P::ident(s, lane), acc);
+    }
+#pragma unroll
+    for (int s = 0; s < P::S32; ++s) xt[t][s] = P::from_acc(acc, s);
+  }
+}
+
+// dW^T tiles of one layer: [in tile n][out tile m] += XT[n] (A, k = points) x dZT[m] (B); bias grads from dZT
+template <class P, int NIN, int NOUT>
+__device__ __forceinline__ void wgrad(float* dw, float* db, int layer, int lane, const typename P::frag (&xt)[NIN][P::S32],
+                                      const typename P::frag (&dzt)[NOUT][P::S32]) {
+#pragma unroll
+  for (int n = 0; n < NIN; ++n) {
+#pragma unroll
+    for (int m = 0; m < NOUT; ++m) {
+      f32x16 acc;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+      for (int s = 0; s < P::S32; ++s) acc = P::mfma(xt[n][s], dzt[m][s], acc);
+      float* t = dw + ((dw_tile_base(layer) + n * NOUT + m) * 16) * 64 + lane;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) atomicAdd(t + q * 64, acc[q]);
+    }
+  }
+}
+
+// bias gradient: sum of the orientation-2 dZ tile over its 16 point registers (two lane halves add up in LDS)
+template <class P>
+__device__ __forceinline__ float frag_sum(const typename P::frag (&f)[P::S32]) {
+  float s = 0.f;
+  if constexpr (P::ELEMS == 8) {
+#pragma unroll
+    for (int k = 0; k < P::S32; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (float)f[k][j];
+  } else {
+#pragma unroll
+    for (int k = 0; k < P::S32; ++k) s += f[k];
+  }
+  return s;
+}
+
+template <class P, int NOUT>
+__device__ __forceinline__ void bgrad(float* db, int layer, int lane, const typename P::frag (&dzt)[NOUT][P::S32]) {
+#pragma unroll
+  for (int m = 0; m < NOUT; ++m) atomicAdd(db + layer * 64 + 32 * m + (lane & 31), frag_sum<P>(dzt[m]));
+}
+
+struct DFeatDst {
+  void* p;
+  int64_t stride;
+};
+
+template <class P, int LAYOUT, int DT, int NWAVES, bool WLDS>
+__global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(const char* __restrict__ gimg, FeatSrc fs, PeSrc ps,
+                                                              const float* __restrict__ dout, DFeatDst dfd,
+                                                              float* __restrict__ dparams) {
+  using T = Tab<P>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* dw = (float*)smem;
+  float* db = (float*)(smem + kDwBytes);
+  char* limg = smem + kDwBytes + kDbBytes;
+  for (int i = threadIdx.x; i < (kDwBytes + kDbBytes) / 4; i += NWAVES * 64) dw[i] = 0.f;
+  if (WLDS) stage_image(limg, gimg, T::IMG_BYTES);
+  __syncthreads();
+  const char* img = WLDS ? (const char*)limg : gimg;
+  const float* bias = (const float*)(img + T::BIAS_OFF_ALL);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5;
+  const uint32_t ntiles = (fs.N + 31) / 32;
+
+  for (uint32_t tile = blockIdx.x * NWAVES + wv; tile < ntiles; tile += gridDim.x * NWAVES) {
+    const uint32_t n = tile * 32 + (lane & 31);
+    const bool valid = n < fs.N;
+    Saved<P> sv;
+    forward_tile<P, LAYOUT, DT>(img, bias, fs, ps, n, valid, lane, sv);
+    float4 dO = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid && h == 0) dO = ((const float4*)dout)[n];
+
+    // ---- C3: dZc3 rows 0..2 = d rgb * elu'(raw)  (elu' = 1 for x>0 else exp(x))
+    typename P::frag dz3[P::S8];
+    {
+      f32x16 a;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) a[q] = 0.f;
+      a[0] = dO.x * (sv.raw[0] > 0.f ? 1.f : expf(sv.raw[0]));
+      a[1] = dO.y * (sv.raw[1] > 0.f ? 1.f : expf(sv.raw[1]));
+      a[2] = dO.z * (sv.raw[2] > 0.f ? 1.f : expf(sv.raw[2]));
+#pragma unroll
+      for (int s = 0; s < P::S8; ++s) dz3[s] = P::from_acc(a, s);
+    }
+    {
+      typename P::frag xt[2][P::S32], zt[1][P::S32];
+      transpose_frags<P, 2, 2 * P::S32>(sv.c2, lane, xt);
+      transpose_frags<P, 1, P::S8>(dz3, lane, zt);
+      wgrad<P, 2, 1>(dw, db, C3, lane, xt, zt);
+      bgrad<P, 1>(db, C3, lane, zt);
+    }
+    // ---- C2
+    typename P::frag dzc2[2 * P::S32];
+    {
+      f32x16 a[2];
+      dense<P, 2, P::S8, false>(img, T::b_base(C3), nullptr, lane, dz3, a);
+      mask_frags<P, 2>(a, sv.mc2, dzc2);
+      typename P::frag xt[2][P::S32], zt[2][P::S32];
+      transpose_frags<P, 2, 2 * P::S32>(sv.c1, lane, xt);
+      transpose_frags<P, 2, 2 * P::S32>(dzc2, lane, zt);
+      wgrad<P, 2, 2>(dw, db, C2, lane, xt, zt);
+      bgrad<P, 2>(db, C2, lane, zt);
+    }
+    // ---- C1
+    typename P::frag dzc1[2 * P::S32];
+    {
+      f32x16 a[2];
+      dense<P, 2, 2 * P::S32, false>(img, T::b_base(C2), nullptr, lane, dzc2, a);
+      mask_frags<P, 2>(a, sv.mc1, dzc1);
+      typename P::frag xt[2][P::S32], zt[2][P::S32];
+      transpose_frags<P, 2, P::S32 + P::S8>(sv.cin, lane, xt);
+      transpose_frags<P, 2, 2 * P::S32>(dzc1, lane, zt);
+      wgrad<P, 2, 2>(dw, db, C1, lane, xt, zt);
+      bgrad<P, 2>(db, C1, lane, zt);
+    }
+    // ---- L3: ds rows 1..15 = d cin slots 1..15 ; row 0 = d sigma * lrelu'(s0)
+    typename P::frag dz_s[P::S16];
+    {
+      f32x16 a[1];
+      dense<P, 1, 2 * P::S32, false>(img, T::b_base(C1), nullptr, lane, dzc1, a);
+      if (h == 0) a[0][0] = dO.w * (sv.s0 > 0.f ? 1.f : 0.01f);
+#pragma unroll
+      for (int s = 0; s < P::S16; ++s) dz_s[s] = P::from_acc(a[0], s);
+      typename P::frag xt[2][P::S32], zt[1][P::S32];
+      transpose_frags<P, 2, 2 * P::S32>(sv.h2, lane, xt);
+      transpose_frags<P, 1, P::S16>(dz_s, lane, zt);
+      wgrad<P, 2, 1>(dw, db, L3, lane, xt, zt);
+      bgrad<P, 1>(db, L3, lane, zt);
+    }
+    // ---- L2
+    typename P::frag dz2[2 * P::S32];
+    {
+      f32x16 a[2];
+      dense<P, 2, P::S16, false>(img, T::b_base(L3), nullptr, lane, dz_s, a);
+      mask_frags<P, 2>(a, sv.m2, dz2);
+      typename P::frag xt[2][P::S32], zt[2][P::S32];
+      transpose_frags<P, 2, 2 * P::S32>(sv.h1, lane, xt);
+      transpose_frags<P, 2, 2 * P::S32>(dz2, lane, zt);
+      wgrad<P, 2, 2>(dw, db, L2, lane, xt, zt);
+      bgrad<P, 2>(db, L2, lane, zt);
+    }
+    // ---- L1
+    typename P::frag dz1[2 * P::S32];
+    {
+      f32x16 a[2];
+      dense<P, 2, 2 * P::S32, false>(img, T::b_base(L2), nullptr, lane, dz2, a);
+      mask_frags<P, 2>(a, sv.m1, dz1);
+      typename P::frag xt[1][P::S32], zt[2][P::S32];
+      transpose_frags<P, 1, P::S32>(sv.x0, lane, xt);
+      transpose_frags<P, 2, 2 * P::S32>(dz1, lane, zt);
+      wgrad<P, 1, 2>(dw, db, L1, lane, xt, zt);
+      bgrad<P, 2>(db, L1, lane, zt);
+    }
+    // ---- d feat
+    if (dfd.p) {
+      f32x16 a[1];
+      dense<P, 1, 2 * P::S32, false>(img, T::b_base(L1), nullptr, lane, dz1, a);
+      if (valid) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          // registers 4g..4g+3 <-> features 8g+4h .. 8g+4h+3 = levels 4g+2h, 4g+2h+1
+          const float v0 = a[0][4 * g], v1 = a[0][4 * g + 1], v2 = a[0][4 * g + 2], v3 = a[0][4 * g + 3];
+          const int lvl = 4 * g + 2 * h;
+          if (LAYOUT == HBR_LAYOUT_PLANAR) {
+            if (DT == HBR_F32) {
+              ((float2*)dfd.p)[(size_t)lvl * fs.N + n] = make_float2(v0, v1);
+              ((float2*)dfd.p)[(size_t)(lvl + 1) * fs.N + n] = make_float2(v2, v3);
+            } else {
+              ((uint32_t*)dfd.p)[(size_t)lvl * fs.N + n] = pack_bf16x2(v0, v1);
+              ((uint32_t*)dfd.p)[(size_t)(lvl + 1) * fs.N + n] = pack_bf16x2(v2, v3);
+            }
+          } else {
+            if (DT == HBR_F32) {
+              *(float4*)((float*)dfd.p + (size_t)n * dfd.stride + 2 * lvl) = make_float4(v0, v1, v2, v3);
+            } else {
+              uint2 u = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+              *(uint2*)((uint16_t*)dfd.p + (size_t)n * dfd.stride + 2 * lvl) = u;
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- flush the workgroup's dW / db image
+  __syncthreads();
+  for (int e = threadIdx.x; e < kDwTiles * 16 * 64; e += NWAVES * 64) {
+    const float v = dw[e];
+    if (v == 0.f) continue;
+    const int ln = e & 63, q = (e >> 6) & 15, tid = e >> 10;
+    int l = NLAYER - 1;
+    while (dw_tile_base(l) > tid) --l;
+    const int nout = (l == L3 || l == C3) ? 1 : 2;
+    const int nin_t = (tid - dw_tile_base(l)) / nout, mout_t = (tid - dw_tile_base(l)) % nout;
+    const int i = 32 * nin_t + acc_row(q, ln >> 5), o = 32 * mout_t + (ln & 31);
+    const int off = wlog_offset(l, o, i);
+    if (off >= 0) unsafeAtomicAdd(dparams + off, v);
+  }
+  for (int e = threadIdx.x; e < NLAYER * 64; e += NWAVES * 64) {
+    const int off = blog_offset(e / 64, e % 64);
+    const float v = db[e];
+    if (off >= 0 && v != 0.f) unsafeAtomicAdd(dparams + off, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// view-direction encoding (a7): out[row, c*2nf + k] = sin(2*x_c*k), out[row, c*2nf + nf + k] = cos(2*x_c*k)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dir_encode_kernel(const float* __restrict__ x, int64_t rows, int d, int nf,
+                                                         float* __restrict__ out) {
+  const int64_t total = rows * d * nf;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int k = (int)(e % nf);
+    const int64_t rc = e / nf;
+    const int c = (int)(rc % d);
+    const int64_t row = rc / d;
+    const float ang = __fmul_rn(__fmul_rn(2.f, x[row * d + c]), (float)k);  // encoder.py:27: (2*x)*k
+    float* o = out + row * (int64_t)(d * 2 * nf) + c * 2 * nf;
+    o[k] = sinf(ang);
+    o[nf + k] = cosf(ang);
+  }
+}
+
+template <class P>
+static int pack(const float* params, char* ws, hipStream_t st) {
+  hipLaunchKernelGGL((pack_kernel<P>), dim3(64), dim3(256), 0, st, params, ws);
+  return HBR_OK;
+}
+
+template <class P, int LAYOUT>
+static void launch_fwd(int dt, uint32_t blocks, hipStream_t st, const char* img, FeatSrc fs, PeSrc ps, float* out) {
+  using T = Tab<P>;
+  const int lds = T::BIAS_OFF_F + T::BIAS_BYTES;
+  if (dt == HBR_F32) {
+    auto k = mlp_fwd_kernel<P, LAYOUT, HBR_F32>;
+    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(kFwdWaves * 64), lds, st, img, fs, ps, out);
+  } else {
+    auto k = mlp_fwd_kernel<P, LAYOUT, HBR_BF16>;
+    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(kFwdWaves * 64), lds, st, img, fs, ps, out);
+  }
+}
+
+template <class P, int LAYOUT, int DT, int NWAVES, bool WLDS>
+static void launch_bwd1(uint32_t ntiles, hipStream_t st, const char* img, FeatSrc fs, PeSrc ps, const float* dout, DFeatDst dfd,
+                        float* dparams) {
+  using T = Tab<P>;
+  const int lds = kDwBytes + kDbBytes + (WLDS ? T::IMG_BYTES : 0);
+  uint32_t blocks = (ntiles + NWAVES - 1) / NWAVES;
+  if (blocks > 256) blocks = 256;  // one workgroup per CU (LDS-bound); each sweeps its share of the tiles
+  auto k = mlp_bwd_kernel<P, LAYOUT, DT, NWAVES, WLDS>;
+  hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(NWAVES * 64), lds, st, img, fs, ps, dout, dfd, dparams);
+}
+
+template <int LAYOUT, int DT>
+static void launch_bwd(int precision, uint32_t ntiles, hipStream_t st, const char* img, FeatSrc fs, PeSrc ps, const float* dout,
+                       DFeatDst dfd, float* dparams) {
+  if (precision == HBR_BF16) launch_bwd1<PBf16, LAYOUT, DT, 8, true>(ntiles, st, img, fs, ps, dout, dfd, dparams);
+  else launch_bwd1<PF32, LAYOUT, DT, 4, false>(ntiles, st, img, fs, ps, dout, dfd, dparams);
+}
+
+static int check_common(const void* feat, int layout, int64_t stride, int dt, const float* pe, int64_t N, int64_t group,
+                        const float* params, int precision, void* ws, int64_t ws_bytes) {
+  if (!feat || !pe || !params || !ws || N < 0 || group < 1) return HBR_EINVAL;
+  if (layout != HBR_LAYOUT_ROWS && layout != HBR_LAYOUT_PLANAR) return HBR_EINVAL;
+  if (dt != HBR_F32 && dt != HBR_BF16) return HBR_EINVAL;
+  if (precision != HBR_F32 && precision != HBR_BF16) return HBR_EINVAL;
+  if (layout == HBR_LAYOUT_ROWS && (stride < 32 || (stride & 3))) return HBR_EINVAL;  // 16-byte row alignment
+  if (N > 0x7fffffffLL) return HBR_EUNSUPPORTED;
+  if (ws_bytes < hbr_mlp_workspace_bytes(precision)) return HBR_EWORKSPACE;
+  if (((uintptr_t)ws | (uintptr_t)pe) & 15) return HBR_EINVAL;
+  return HBR_OK;
+}
+
+}  // namespace mlp
+}  // namespace hbr
+
+using namespace hbr;
+using namespace hbr::mlp;
+
+extern "C" int64_t hbr_mlp_workspace_bytes(int precision) {
+  return precision == HBR_BF16 ? Tab<PBf16>::IMG_BYTES : Tab<PF32>::IMG_BYTES;
+}
+
+extern "C" int hbr_dir_encode(const float* x, int64_t rows, int d_model, int num_freq, float* out, void* stream) {
+  if (!x || !out || rows < 0 || d_model < 1 || num_freq < 1) return HBR_EINVAL;
+  if (rows == 0) return HBR_OK;
+  int64_t total = rows * d_model * num_freq;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(dir_encode_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, x, rows, d_model, num_freq, out);
+  HBR_RETURN_IF_LAUNCH_FAILED();
+  return HBR_OK;
+}
+
+extern "C" int hbr_mlp_fwd(const void* feat, int layout, int64_t feat_stride, int feat_dtype, const float* viewdirs_enc,
+                           int64_t N, int64_t group, const float* params, int precision, float* out, void* ws, int64_t ws_bytes,
+                           void* stream) {
+  int rc = check_common(feat, layout, feat_stride, feat_dtype, viewdirs_enc, N, group, params, precision, ws, ws_bytes);
+  if (rc) return rc;
+  if (!out || ((uintptr_t)out & 15)) return HBR_EINVAL;
+  if (N == 0) return HBR_OK;
+  hipStream_t st = (hipStream_t)stream;
+  FeatSrc fs{feat, feat_stride, (uint32_t)N};
+  PeSrc ps{viewdirs_enc, (uint32_t)group};
+  const uint32_t ntiles = (uint32_t)((N + 31) / 32);
+  uint32_t blocks = (ntiles + kFwdWaves - 1) / kFwdWaves;
+  if (blocks > 1024) blocks = 1024;
+  char* img = (char*)ws;
+  if (precision == HBR_BF16) {
+    pack<PBf16>(params, img, st);
+    if (layout == HBR_LAYOUT_PLANAR) launch_fwd<PBf16, HBR_LAYOUT_PLANAR>(feat_dtype, blocks, st, img, fs, ps, out);
+    else launch_fwd<PBf16, HBR_LAYOUT_ROWS>(feat_dtype, blocks, st, img, fs, ps, out);
+  } else {
+    pack<PF32>(params, img, st);
+    if (layout == HBR_LAYOUT_PLANAR) launch_fwd<PF32, HBR_LAYOUT_PLANAR>(feat_dtype, blocks, st, img, fs, ps, out);
+    else launch_fwd<PF32, HBR_LAYOUT_ROWS>(feat_dtype, blocks, st, img, fs, ps, out);
+  }
+  HBR_RETURN_IF_LAUNCH_FAILED();
+  return HBR_OK;
+}
+
+extern "C" int hbr_mlp_bwd(const void* feat, int layout, int64_t feat_stride, int feat_dtype, const float* viewdirs_enc,
+                           int64_t N, int64_t group, const float* params, int precision, const float* dout, void* dfeat,
+                           float* dparams, void* ws, int64_t ws_bytes, void* stream) {
+  int rc = check_common(feat, layout, feat_stride, feat_dtype, viewdirs_enc, N, group, params, precision, ws, ws_bytes);
+  if (rc) return rc;
+  if (!dout || !dparams || ((uintptr_t)dout & 15)) return HBR_EINVAL;
+  if (N == 0) return HBR_OK;
+  hipStream_t st = (hipStream_t)stream;
+  FeatSrc fs{feat, feat_stride, (uint32_t)N};
+  PeSrc ps{viewdirs_enc, (uint32_t)group};
+  DFeatDst dfd{dfeat, feat_stride};
+  const uint32_t ntiles = (uint32_t)((N + 31) / 32);
+  char* img = (char*)ws;
+  if (precision == HBR_BF16) pack<PBf16>(params, img, st);
+  else pack<PF32>(params, img, st);
+  if (layout == HBR_LAYOUT_PLANAR) {
+    if (feat_dtype == HBR_F32) launch_bwd<HBR_LAYOUT_PLANAR, HBR_F32>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams);
+    else launch_bwd<HBR_LAYOUT_PLANAR, HBR_BF16>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams);
+  } else {
+    if (feat_dtype == HBR_F32) launch_bwd<HBR_LAYOUT_ROWS, HBR_F32>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams);
+    else launch_bwd<HBR_LAYOUT_ROWS, HBR_BF16>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams);
+  }
+  HBR_RETURN_IF_LAUNCH_FAILED();
+  return HBR_OK;
+}

@@ -1,0 +1,309 @@
+"""Tensor-level wrappers over the C ABI (include/hbr_hip.h) and the autograd Functions built on them.
+
+PyTorch here is plumbing: device memory, streams, autograd bookkeeping.  All arithmetic of the hot
+path runs in libhbr_hip.so.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, PLANAR, ROWS, check, lib, require_gpu
+
+_ws_cache = {}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _mlp_ws(precision: int, device) -> torch.Tensor:
+    key = (precision, device)
+    ws = _ws_cache.get(key)
+    if ws is None:
+        ws = torch.empty(lib().hbr_mlp_workspace_bytes(precision) + 64, dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+@dataclass(frozen=True)
+class HashGeom:
+    """Host-side description of the grid: fp32 level scales (computed with the reference's torch ops),
+    bbox origin mu, bbox diagonal sigma, table rows T, features F."""
+    scales: Tuple[float, ...]
+    mu: Tuple[float, float, float]
+    sigma: float
+    T: int
+    F: int = 2
+
+    @property
+    def L(self) -> int:
+        return len(self.scales)
+
+    def c_args(self):
+        import ctypes as C
+        sc = (C.c_float * self.L)(*self.scales)
+        mu = (C.c_float * 3)(*self.mu)
+        return sc, mu
+
+
+def precision_from_autocast() -> int:
+    """The reference runs vol_render under torch.cuda.amp.autocast() (train_hash2.py:218): Linear layers
+    drop to half precision there and stay fp32 otherwise.  Same switch here: bf16 MFMA under autocast,
+    exact-fp32 MFMA outside."""
+    return BF16 if torch.is_autocast_enabled() else F32
+
+
+# --------------------------------------------------------------------------------------------------
+# raw ops
+# --------------------------------------------------------------------------------------------------
+def hash_encode_fwd(geom: HashGeom, tables: torch.Tensor, x: Optional[torch.Tensor] = None, rays=None,
+                    layout: int = ROWS, out: Optional[torch.Tensor] = None, dtype: int = F32, extra_cols: int = 0):
+    """tables [L,T,F] fp32.  Either x [N,3] or rays=(o[R,3], d[R,3], t[S])."""
+    require_gpu(tables)
+    if x is not None:
+        x = _f32c(x)
+        R, S = x.shape[0], 1
+        o = d = t = None
+    else:
+        o, d, t = (_f32c(a) for a in rays)
+        R, S = o.shape[0], t.shape[0]
+    N, L, F = R * S, geom.L, geom.F
+    tdt = torch.float32 if dtype == F32 else torch.bfloat16
+    if out is None:
+        if layout == PLANAR:
+            out = torch.empty((L, N, F), dtype=tdt, device=tables.device)
+        else:
+            out = torch.zeros((N, L * F + extra_cols), dtype=tdt, device=tables.device) if extra_cols else \
+                torch.empty((N, L * F), dtype=tdt, device=tables.device)
+    stride = out.shape[-1] if layout == ROWS else 0
+    sc, mu = geom.c_args()
+    check(lib().hbr_hash_encode_fwd(_ptr(x), _ptr(o), _ptr(d), _ptr(t), R, S, tables.data_ptr(), sc, mu, geom.sigma,
+                                    L, geom.T, F, out.data_ptr(), layout, stride, dtype, _stream()), "hbr_hash_encode_fwd")
+    return out
+
+
+def hash_encode_bwd(geom: HashGeom, dy: torch.Tensor, dtables: torch.Tensor, x: Optional[torch.Tensor] = None, rays=None,
+                    layout: int = ROWS, algo: int = 0):
+    """Accumulates into dtables [L,T,F] fp32."""
+    require_gpu(dy)
+    if x is not None:
+        x = _f32c(x)
+        R, S = x.shape[0], 1
+        o = d = t = None
+    else:
+        o, d, t = (_f32c(a) for a in rays)
+        R, S = o.shape[0], t.shape[0]
+    if not dy.is_contiguous():
+        dy = dy.contiguous()
+    dtype = F32 if dy.dtype == torch.float32 else BF16
+    stride = dy.shape[-1] if layout == ROWS else 0
+    sc, mu = geom.c_args()
+    check(lib().hbr_hash_encode_bwd(_ptr(x), _ptr(o), _ptr(d), _ptr(t), R, S, dy.data_ptr(), layout, stride, dtype, sc, mu,
+                                    geom.sigma, geom.L, geom.T, geom.F, dtables.data_ptr(), algo, None, 0, _stream()),
+          "hbr_hash_encode_bwd")
+    return dtables
+
+
+def dir_encode(x: torch.Tensor, num_freq: int) -> torch.Tensor:
+    require_gpu(x)
+    lead, d = x.shape[:-1], x.shape[-1]
+    xf = _f32c(x).reshape(-1, d)
+    out = torch.empty((xf.shape[0], d * 2 * num_freq), dtype=torch.float32, device=x.device)
+    check(lib().hbr_dir_encode(xf.data_ptr(), xf.shape[0], d, num_freq, out.data_ptr(), _stream()), "hbr_dir_encode")
+    return out.reshape(*lead, d * 2 * num_freq)
+
+
+def _feat_desc(feat: torch.Tensor, layout: int):
+    dtype = F32 if feat.dtype == torch.float32 else BF16
+    if layout == PLANAR:
+        N = feat.shape[1]
+        stride = 0
+    else:
+        N = feat.shape[0]
+        stride = feat.stride(0)
+    return N, stride, dtype
+
+
+def mlp_fwd(feat: torch.Tensor, layout: int, viewdirs_enc: torch.Tensor, group: int, params: torch.Tensor, precision: int):
+    require_gpu(feat)
+    N, stride, dtype = _feat_desc(feat, layout)
+    out = torch.empty((N, 4), dtype=torch.float32, device=feat.device)
+    ws = _mlp_ws(precision, feat.device)
+    check(lib().hbr_mlp_fwd(feat.data_ptr(), layout, stride, dtype, viewdirs_enc.data_ptr(), N, group, params.data_ptr(),
+                            precision, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "hbr_mlp_fwd")
+    return out
+
+
+def mlp_bwd(feat: torch.Tensor, layout: int, viewdirs_enc: torch.Tensor, group: int, params: torch.Tensor, precision: int,
+            dout: torch.Tensor, dparams: torch.Tensor, need_dfeat: bool = True):
+    N, stride, dtype = _feat_desc(feat, layout)
+    dfeat = torch.empty_like(feat) if need_dfeat else None
+    ws = _mlp_ws(precision, feat.device)
+    dout = _f32c(dout)
+    check(lib().hbr_mlp_bwd(feat.data_ptr(), layout, stride, dtype, viewdirs_enc.data_ptr(), N, group, params.data_ptr(),
+                            precision, dout.data_ptr(), _ptr(dfeat), dparams.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+          "hbr_mlp_bwd")
+    return dfeat
+
+
+def composite_fwd(t, rgb, rgb_stride, sigma, sigma_stride, dir_norm, R, S, want_wts=True):
+    Cr = torch.empty((R, 3), dtype=torch.float32, device=t.device)
+    wts = torch.empty((R, S), dtype=torch.float32, device=t.device) if want_wts else None
+    check(lib().hbr_composite_fwd(t.data_ptr(), rgb, rgb_stride, sigma, sigma_stride, _ptr(dir_norm), R, S, Cr.data_ptr(),
+                                  _ptr(wts), _stream()), "hbr_composite_fwd")
+    return Cr, wts
+
+
+def composite_bwd(t, rgb, rgb_stride, sigma, sigma_stride, dir_norm, R, S, dCr, d_rgb, d_sigma):
+    check(lib().hbr_composite_bwd(t.data_ptr(), rgb, rgb_stride, sigma, sigma_stride, _ptr(dir_norm), R, S, dCr.data_ptr(),
+                                  d_rgb, d_sigma, _stream()), "hbr_composite_bwd")
+
+
+def mse2_loss(Cr: torch.Tensor, gt: torch.Tensor, gscale: float = 1.0, want_grad: bool = True):
+    """loss = 2*mean((Cr-gt)^2) (train_hash2.py:221, hierarchical off) and dloss/dCr * gscale."""
+    require_gpu(Cr)
+    Cr, gt = _f32c(Cr), _f32c(gt)
+    loss = torch.zeros((), dtype=torch.float32, device=Cr.device)
+    dCr = torch.empty_like(Cr) if want_grad else None
+    check(lib().hbr_mse2_loss_fwd_bwd(Cr.data_ptr(), gt.data_ptr(), Cr.shape[0], gscale, loss.data_ptr(), _ptr(dCr), _stream()),
+          "hbr_mse2_loss_fwd_bwd")
+    return loss, dCr
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    require_gpu(p)
+    check(lib().hbr_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
+                              weight_decay, step, grad_scale, _stream()), "hbr_adam_step")
+
+
+def _dir_norm_arg(dir_norm, R, device):
+    """dir_norm: [R,1]/[R] tensor, python scalar, or 0-d tensor (vol_render's default is the int 1)."""
+    if dir_norm is None:
+        return None
+    if torch.is_tensor(dir_norm):
+        if dir_norm.numel() == 1:
+            v = float(dir_norm)
+            return None if v == 1.0 else torch.full((R,), v, dtype=torch.float32, device=device)
+        return _f32c(dir_norm).reshape(R)
+    v = float(dir_norm)
+    return None if v == 1.0 else torch.full((R,), v, dtype=torch.float32, device=device)
+
+
+# --------------------------------------------------------------------------------------------------
+# autograd Functions
+# --------------------------------------------------------------------------------------------------
+class HashEncodeFn(torch.autograd.Function):
+    """y[N, L*F+E] = HashEncoder.forward(x) (hash_encoding.py:146-170).  No gradient flows to x
+    (the reference detaches the fractional part, :160)."""
+
+    @staticmethod
+    def forward(ctx, x, stacked, geom, extra_cols, *weights):
+        ctx.geom, ctx.x = geom, x.detach()
+        ctx.nw = len(weights)
+        return hash_encode_fwd(geom, stacked, x=ctx.x, layout=ROWS, extra_cols=extra_cols)
+
+    @staticmethod
+    def backward(ctx, dy):
+        g = ctx.geom
+        dtab = torch.zeros((g.L, g.T, g.F), dtype=torch.float32, device=dy.device)
+        LF = g.L * g.F
+        dyc = dy if dy.shape[-1] == LF else dy[:, :LF]
+        hash_encode_bwd(g, dyc.contiguous(), dtab, x=ctx.x, layout=ROWS)
+        return (None, None, None, None) + tuple(dtab[i] for i in range(ctx.nw))
+
+
+class MlpFn(torch.autograd.Function):
+    """out[N,4] = MLP_3D.forward(feat, viewdirs_enc) (test_hash.py:52-72)."""
+
+    @staticmethod
+    def forward(ctx, feat, viewdirs_enc, group, flat, precision, splits, *params):
+        feat_c = feat.detach()
+        if feat_c.dtype != torch.float32:
+            feat_c = feat_c.float()
+        if feat_c.stride(-1) != 1 or feat_c.stride(0) % 4 or feat_c.data_ptr() % 16:
+            feat_c = feat_c.contiguous()
+        pe = _f32c(viewdirs_enc.detach())
+        ctx.save_for_backward(feat_c, pe)
+        ctx.flat, ctx.group, ctx.precision, ctx.splits = flat, group, precision, splits
+        ctx.need_dfeat = feat.requires_grad
+        return mlp_fwd(feat_c, ROWS, pe, group, flat, precision)
+
+    @staticmethod
+    def backward(ctx, dout):
+        feat, pe = ctx.saved_tensors
+        dflat = torch.zeros_like(ctx.flat)
+        dfeat = mlp_bwd(feat, ROWS, pe, ctx.group, ctx.flat, ctx.precision, dout, dflat, need_dfeat=ctx.need_dfeat)
+        grads = tuple(dflat[a:b].view(shape) for (a, b, shape) in ctx.splits)
+        return (dfeat, None, None, None, None, None) + grads
+
+
+class CompositeFn(torch.autograd.Function):
+    """Cr, wts = calc_color(t, rgb, sigma, dir_norm) (helper.py:53-107)."""
+
+    @staticmethod
+    def forward(ctx, t, rgb, sigma, dir_norm):
+        R, S = sigma.shape
+        t, rgb, sigma = _f32c(t.detach()), _f32c(rgb.detach()), _f32c(sigma.detach())
+        dn = _dir_norm_arg(dir_norm, R, sigma.device)
+        Cr, wts = composite_fwd(t, rgb.data_ptr(), 3, sigma.data_ptr(), 1, dn, R, S)
+        ctx.save_for_backward(t, rgb, sigma)
+        ctx.dn = dn
+        ctx.mark_non_differentiable(wts)
+        return Cr, wts
+
+    @staticmethod
+    def backward(ctx, dCr, _dw):
+        t, rgb, sigma = ctx.saved_tensors
+        R, S = sigma.shape
+        d_rgb, d_sigma = torch.empty_like(rgb), torch.empty_like(sigma)
+        composite_bwd(t, rgb.data_ptr(), 3, sigma.data_ptr(), 1, ctx.dn, R, S, _f32c(dCr), d_rgb.data_ptr(), d_sigma.data_ptr())
+        return None, d_rgb, d_sigma, None
+
+
+class RenderFn(torch.autograd.Function):
+    """The whole of vol_render (vol_renderer.py:141-245, hierarchical off, all-true occupancy mask):
+    rays -> points -> hash features (planar) -> MLP -> composite, with one hand-written backward:
+    composite_bwd -> mlp_bwd (recomputes activations) -> hash scatter-add.  Nothing but the planar
+    feature buffer and the [N,4] MLP output is kept between forward and backward."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, t, dir_norm, geom, stacked, flat, precision, num_freq, splits, feat_dtype, n_tab, *params):
+        o, d, t = _f32c(rays_o.detach()), _f32c(rays_d.detach()), _f32c(t.detach())
+        R, S = o.shape[0], t.shape[0]
+        dn = _dir_norm_arg(dir_norm, R, o.device)
+        pe = dir_encode(d, num_freq)
+        feat = hash_encode_fwd(geom, stacked, rays=(o, d, t), layout=PLANAR, dtype=feat_dtype)
+        out = mlp_fwd(feat, PLANAR, pe, S, flat, precision)
+        Cr, wts = composite_fwd(t, out.data_ptr(), 4, out.data_ptr() + 12, 4, dn, R, S)
+        ctx.save_for_backward(o, d, t, pe, feat, out)
+        ctx.dn, ctx.geom, ctx.flat, ctx.precision, ctx.splits, ctx.n_tab = dn, geom, flat, precision, splits, n_tab
+        ctx.mark_non_differentiable(wts, out)
+        return Cr, wts, out
+
+    @staticmethod
+    def backward(ctx, dCr, _dw, _dout):
+        o, d, t, pe, feat, out = ctx.saved_tensors
+        g = ctx.geom
+        R, S = o.shape[0], t.shape[0]
+        d_out = torch.empty_like(out)
+        composite_bwd(t, out.data_ptr(), 4, out.data_ptr() + 12, 4, ctx.dn, R, S, _f32c(dCr), d_out.data_ptr(), d_out.data_ptr() + 12)
+        dflat = torch.zeros_like(ctx.flat)
+        dfeat = mlp_bwd(feat, PLANAR, pe, S, ctx.flat, ctx.precision, d_out, dflat)
+        dtab = torch.zeros((g.L, g.T, g.F), dtype=torch.float32, device=o.device)
+        hash_encode_bwd(g, dfeat, dtab, rays=(o, d, t), layout=PLANAR)
+        grads = tuple(dtab[i] for i in range(ctx.n_tab)) + tuple(dflat[a:b].view(shape) for (a, b, shape) in ctx.splits)
+        return (None,) * 12 + grads

@@ -1,0 +1,135 @@
+"""Volume_Renderer: the reference's renderer object (vol_renderer.py:88-245) on the gfx950 pipeline.
+
+`vol_render(model, rays_d, rays_o, ...)` keeps the reference's argument order (rays_d BEFORE rays_o),
+defaults and return triple (Cr, Cf, norm).  With a hbr_amd HashEncoder + PositionalEncoder(3,4) + MLP_3D it
+runs the fused path (ops.RenderFn): points are generated on chip from (o, d, t), features never take
+the [N,32] row layout, and the backward pass is three hand-written kernels.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import F32, HbrError
+from .encoder import PositionalEncoder
+from .hash_encoding import HashEncoder
+from .helper import calc_color, strat_sampler
+from .test_hash import MLP_3D
+
+
+def _unwrap(model):
+    return model.module if isinstance(model, (nn.DataParallel, nn.parallel.DistributedDataParallel)) else model
+
+
+class Volume_Renderer():
+    def __init__(self, H, W, K, near=0., far=1., device=None, Pos_encode: Optional[HashEncoder] = None,
+                 Dir_encode: Optional[PositionalEncoder] = None, max_dim=1024, sigma_val=torch.as_tensor(1),
+                 mu=torch.as_tensor(0), use_sdf: Optional[bool] = False, var_model: Optional[nn.Module] = None):
+        self.H, self.W, self.K = H, W, K
+        self.near, self.far = near, far
+        self.device = device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu")
+        self.Pos_encode, self.Dir_encode = Pos_encode, Dir_encode
+        self.grid_size = max_dim // 4
+        g = self.grid_size
+        # occupancy grid: all ones and never updated by the shipped trainer; kept for API parity
+        self.bool_grid = torch.ones((g, g, g), device=self.device, dtype=torch.bool)
+        self.tmp_arr = torch.zeros((g, g, g), device=self.device, dtype=torch.int8)
+        self.sigma_val = sigma_val.to(self.device) if torch.is_tensor(sigma_val) else torch.as_tensor(sigma_val, device=self.device)
+        self.mu = mu.to(self.device) if torch.is_tensor(mu) else torch.as_tensor(mu, device=self.device)
+        self.epislon = 1e-5
+        self.reset_mask = False
+        self.use_sdf = use_sdf
+        self.var_model = var_model
+        self.feat_dtype = F32       # dtype of the planar feature buffer between K1 and K3 (F32 | BF16)
+        self._grid_version = self.bool_grid._version
+        self._grid_all_true = True
+        self.last_sigma = None      # [R,S] / [R,S,3] views of the last MLP output, for inspection and parity tests
+        self.last_rgb = None
+
+    # ---- occupancy grid (vol_renderer.py:116-140) ---------------------------------------------
+    def _cell(self, points):
+        p = (points - self.mu) / self.sigma_val
+        return (p * self.grid_size).long()
+
+    def update_grid(self, points: torch.Tensor, alpha: torch.Tensor):
+        idx = self._cell(points)
+        alpha = torch.where(alpha <= 0, torch.zeros_like(alpha), alpha)
+        self.tmp_arr[idx[..., 0], idx[..., 1], idx[..., 2]] += torch.ceil(alpha).to(torch.int8)
+        if torch.sum(self.tmp_arr > 0) == 0:
+            self.bool_grid[...] = True
+        else:
+            self.bool_grid[self.tmp_arr > 0] = True
+        self.tmp_arr[self.tmp_arr > 0] = 0
+
+    def get_mask(self, points: torch.Tensor) -> torch.Tensor:
+        idx = self._cell(points)
+        return self.bool_grid[idx[..., 0], idx[..., 1], idx[..., 2]]
+
+    def _mask_is_trivial(self) -> bool:
+        if self.bool_grid._version != self._grid_version:
+            self._grid_all_true = bool(self.bool_grid.all())
+            self._grid_version = self.bool_grid._version
+        return self._grid_all_true
+
+    # ---- render (vol_renderer.py:141-245) -----------------------------------------------------
+    def vol_render(self, model, rays_d: torch.Tensor, rays_o: torch.Tensor, num_samples=100, t: Optional[torch.Tensor] = None,
+                   update_mask=False, dir_norm=1, hierarchical=True):
+        enc, denc, mlp = self.Pos_encode, self.Dir_encode, _unwrap(model)
+        if enc is None:
+            print("ERROR: No positional encoding")  # vol_renderer.py:192
+            raise NameError("mask")
+        if not (isinstance(enc, HashEncoder) and isinstance(denc, PositionalEncoder) and isinstance(mlp, MLP_3D)):
+            raise NotImplementedError("hbr_amd.Volume_Renderer accelerates the hash path only: Pos_encode=hbr_amd HashEncoder, "
+                                      "Dir_encode=hbr_amd PositionalEncoder(3, num_freq=4), model=hbr_amd MLP_3D; the vanilla "
+                                      "positional-encoding NeRF of train.py is out of scope")
+        if denc.d_model != 3 or denc.max_seq_len != 4:
+            raise NotImplementedError("direction encoder must be PositionalEncoder(d_model=3, num_freq=4) (train_hash2.py:46,121)")
+        if not rays_d.is_cuda:
+            raise HbrError("vol_render needs rays on the MI355X; there is no CPU fallback")
+        if t is None:
+            t = strat_sampler(self.near, self.far, num_samples, device=rays_d.device)
+        if update_mask is True and self.reset_mask is True:  # vol_renderer.py:201-203
+            self.bool_grid[...] = False
+            self.reset_mask = False
+        if update_mask is not True and not self._mask_is_trivial():
+            Cr = self._render_masked(mlp, rays_d, rays_o, t, dir_norm)
+        else:
+            Cr = self._render_fused(mlp, rays_d, rays_o, t, dir_norm)
+        if hierarchical is True:
+            from .hierarchical import render_fine
+            Cf = render_fine(self, mlp, rays_d, rays_o, t, self._last_wts, num_samples, dir_norm)
+        else:
+            Cf = Cr
+        return Cr, Cf, None
+
+    def _render_fused(self, mlp, rays_d, rays_o, t, dir_norm):
+        enc = self.Pos_encode
+        stacked = enc.stacked_tables()
+        flat, splits = mlp.flat_params()
+        tabs = [lvl.weight for lvl in enc.Embedding_list]
+        Cr, wts, out = ops.RenderFn.apply(rays_o, rays_d, t, dir_norm, enc.geometry(), stacked, flat,
+                                          ops.precision_from_autocast(), self.Dir_encode.max_seq_len, splits, self.feat_dtype,
+                                          len(tabs), *tabs, *mlp._ordered())
+        R, S = rays_o.shape[0], t.shape[0]
+        self._last_wts = wts
+        o4 = out.view(R, S, 4)
+        self.last_sigma, self.last_rgb = o4[..., 3], o4[..., 0:3]
+        return Cr
+
+    def _render_masked(self, mlp, rays_d, rays_o, t, dir_norm):
+        """The reference's masked branch (vol_renderer.py:211-221) for a non-trivial occupancy grid: samples whose
+        grid cell is False contribute sigma = rgb = 0.  Composed from the modular ops (encoder rows layout)."""
+        R, S = rays_o.shape[0], t.shape[0]
+        pts = (rays_o[..., None, :] + rays_d[..., None, :] * t[None, :, None]).reshape(-1, 3)
+        mask = self.get_mask(pts)
+        feat = self.Pos_encode(pts)
+        dirs = self.Dir_encode(rays_d[:, None, :].expand(R, S, 3).reshape(-1, 3))
+        out = mlp(feat, dirs) * mask[:, None]
+        sigma, rgb = out[:, 3].reshape(R, S), out[:, 0:3].reshape(R, S, 3)
+        Cr, wts, _ = calc_color(t, rgb, sigma, dir_norm)
+        self._last_wts = wts[..., 0]
+        self.last_sigma, self.last_rgb = sigma, rgb
+        return Cr

@@ -1,0 +1,152 @@
+/* libhbr_hip.so -- C ABI of the MI355X (gfx950) hash-NeRF render/train hot path.
+ *
+ * The reference (RishabhSri14/Human-Body-Reconstruction) is 100 % Python and exposes no FFI;
+ * its boundary is a set of Python call signatures.  Each entry point below replaces the chain of
+ * ATen ops behind one of those calls (reference file:line cited per function).  INTEGRATION.md
+ * shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions (all entry points):
+ *   - return 0 on success, a negative HBR_E* code otherwise; never throw, never allocate,
+ *     never synchronise: the caller passes outputs and workspace, work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the null stream);
+ *   - pointers are DEVICE pointers to contiguous row-major buffers unless the parameter name
+ *     ends in `_host`;
+ *   - sizes are int64_t; N = R*S points are ordered ray-major (n = r*S + s);
+ *   - fp32 arithmetic follows the reference's op order (no FMA contraction on the index path).
+ */
+#ifndef HBR_HIP_H
+#define HBR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HBR_VERSION 100 /* 0.1.0 */
+
+enum {
+  HBR_OK = 0,
+  HBR_EINVAL = -1,       /* null pointer / negative size / inconsistent shape */
+  HBR_EUNSUPPORTED = -2, /* configuration outside what the kernels are built for */
+  HBR_ELAUNCH = -3,      /* hipLaunchKernel / hipMemsetAsync reported an error */
+  HBR_EWORKSPACE = -4    /* workspace too small (see hbr_workspace_bytes) */
+};
+
+enum { HBR_MAX_LEVELS = 32 };
+
+/* feature-buffer layouts produced by the encoder and consumed by the MLP kernels */
+enum {
+  HBR_LAYOUT_ROWS = 0,  /* y[n*stride + l*F + f]            (what HashEncoder.forward returns) */
+  HBR_LAYOUT_PLANAR = 1 /* y[(l*N + n)*F + f]  level-major  (coalesced; internal pipeline)     */
+};
+
+enum { HBR_F32 = 0, HBR_BF16 = 1 };
+
+int hbr_version(void);
+const char* hbr_strerror(int code);
+/* 1 if a HIP device with gcnArchName gfx950 is visible, 0 otherwise */
+int hbr_device_ok(void);
+
+/* ---- K1: multiresolution hash-grid encode --------------------------------------------------
+ * Replaces HashEncoder.forward, hash_encoding.py:146-170 (per level: scale :153-154, trunc :157,
+ * frac :158, 8 corners :135, spatial hash :49-53, embedding gather :163, trilinear :142-144).
+ *   x        [N,3] fp32 points (may be NULL when rays are given, see below)
+ *   rays_o/rays_d [R,3], t [S]: if x == NULL the points are generated on chip as
+ *            o + d*t (vol_renderer.py:165), N = R*S
+ *   tables   [L,T,F] fp32, stacked Embedding_list[l].weight
+ *   scales_host [L] fp32 level scales N_l computed by the host exactly as hash_encoding.py:13,153
+ *   mu_host  [3], sigma: un_x = ((x-mu)/sigma)*N_l
+ *   T        rows per level; any T>=1 (power of two takes the uint32 fast path)
+ *   F        features per row: 2
+ *   y        output, layout per `layout`; row stride `y_stride` elements for HBR_LAYOUT_ROWS
+ *            (>= L*F; extra columns are left untouched -- the reference's E aux columns)
+ */
+int hbr_hash_encode_fwd(const float* x, const float* rays_o, const float* rays_d, const float* t,
+                        int64_t R, int64_t S, const float* tables, const float* scales_host,
+                        const float* mu_host, float sigma, int L, int64_t T, int F, void* y,
+                        int layout, int64_t y_stride, int y_dtype, void* stream);
+
+/* ---- K2: gradient scatter-add into the tables ------------------------------------------------
+ * Replaces autograd of the above (16x aten::embedding_dense_backward + mul/sum backward).
+ *   dy       same layout/dtype conventions as y
+ *   dtables  [L,T,F] fp32, ACCUMULATED INTO (caller zeroes it when a fresh gradient is wanted)
+ *   algo     0 = auto, 1 = global float atomics, 2 = LDS-partitioned accumulate + slab flush
+ *   ws       workspace (hbr_hash_bwd_workspace_bytes), may be NULL when that returns 0
+ */
+int hbr_hash_encode_bwd(const float* x, const float* rays_o, const float* rays_d, const float* t,
+                        int64_t R, int64_t S, const void* dy, int layout, int64_t dy_stride,
+                        int dy_dtype, const float* scales_host, const float* mu_host, float sigma,
+                        int L, int64_t T, int F, float* dtables, int algo, void* ws,
+                        int64_t ws_bytes, void* stream);
+int64_t hbr_hash_bwd_workspace_bytes(int64_t N, int L, int64_t T, int F, int algo);
+
+/* ---- K5: alpha compositing along rays ---------------------------------------------------------
+ * Replaces calc_color, helper.py:53-107 (non-SDF branch).
+ *   t [S] shared sample depths; rgb [R,S,3]; sigma [R,S]; dir_norm [R] (NULL => 1)
+ *   rgbs: alternatively rgb and sigma interleaved as the MLP's [R*S,4] (r,g,b,sigma) output:
+ *         pass rgb = out, sigma = out+3 and elem strides rgb_stride = sigma_stride = 4
+ *   Cr [R,3]; wts [R,S] (may be NULL)
+ */
+int hbr_composite_fwd(const float* t, const float* rgb, int64_t rgb_stride, const float* sigma,
+                      int64_t sigma_stride, const float* dir_norm, int64_t R, int64_t S, float* Cr,
+                      float* wts, void* stream);
+/* d_rgb / d_sigma use the same strides as their forward counterparts */
+int hbr_composite_bwd(const float* t, const float* rgb, int64_t rgb_stride, const float* sigma,
+                      int64_t sigma_stride, const float* dir_norm, int64_t R, int64_t S,
+                      const float* dCr, float* d_rgb, float* d_sigma, void* stream);
+
+/* ---- a7: view-direction encoding ---------------------------------------------------------------
+ * Replaces PositionalEncoder.forward, encoder.py:25-32: for each row and coordinate c,
+ * out[row, c*2nf + k] = sin(2*x_c*k), out[row, c*2nf + nf + k] = cos(2*x_c*k), k = 0..nf-1.
+ *   x [rows, d_model] fp32 -> out [rows, d_model*2*num_freq] fp32 */
+int hbr_dir_encode(const float* x, int64_t rows, int d_model, int num_freq, float* out, void* stream);
+
+/* ---- K3/K4: fused density/colour MLP on the matrix cores --------------------------------------
+ * Replaces MLP_3D.forward (test_hash.py:52-72) for the instance built at train_hash2.py:127
+ * (32 -> 64 -> 64 -> 16 ; 15+24 -> 64 -> 64 -> 3; LeakyReLU(0.01) density, ELU rgb).
+ *   feat     [N,32] features (layout/dtype as produced by K1; HBR_LAYOUT_ROWS needs stride % 4 == 0)
+ *   viewdirs_enc [G,24] fp32 encoded view directions (hbr_dir_encode with d_model 3, num_freq 4);
+ *            point n uses row n / group  (group = S for one row per ray, 1 for one row per point)
+ *   params   fp32 flat parameter block, nn.Linear layout, in this order:
+ *            sig0.W[64,32] sig0.b[64] sig2.W[64,64] sig2.b[64] sig4.W[16,64] sig4.b[16]
+ *            col0.W[64,39] col0.b[64] col2.W[64,64] col2.b[64] col4.W[3,64] col4.b[3]   (14227 floats)
+ *   precision HBR_F32 (exact-fp32 MFMA, v_mfma_f32_32x32x2_f32) or HBR_BF16 (bf16 operands, fp32 accumulate)
+ *   out      [N,4] fp32 (r,g,b,sigma)
+ *   ws       scratch of hbr_mlp_workspace_bytes(precision) bytes, 16-byte aligned (holds the weights
+ *            re-packed in MFMA-fragment order; rebuilt on every call, nothing is cached)
+ */
+enum { HBR_MLP_PARAM_FLOATS = 14227 };
+int64_t hbr_mlp_workspace_bytes(int precision);
+int hbr_mlp_fwd(const void* feat, int layout, int64_t feat_stride, int feat_dtype,
+                const float* viewdirs_enc, int64_t N, int64_t group, const float* params,
+                int precision, float* out, void* ws, int64_t ws_bytes, void* stream);
+/* backward: recomputes the forward activations from `feat`, then
+ *   dout     [N,4] fp32 gradient of out
+ *   dfeat    gradient wrt feat (same layout/dtype/stride as feat); may be NULL
+ *   dparams  [14227] fp32, ACCUMULATED INTO
+ */
+int hbr_mlp_bwd(const void* feat, int layout, int64_t feat_stride, int feat_dtype,
+                const float* viewdirs_enc, int64_t N, int64_t group, const float* params,
+                int precision, const float* dout, void* dfeat, float* dparams, void* ws,
+                int64_t ws_bytes, void* stream);
+
+/* ---- a11: loss + its gradient -----------------------------------------------------------------
+ * train_hash2.py:177,221 with hierarchical off: loss = 2*mean((Cr-gt)^2); dCr = 4*(Cr-gt)/(3R) * gscale.
+ * loss_out: one fp32, accumulated into (caller zeroes).  */
+int hbr_mse2_loss_fwd_bwd(const float* Cr, const float* gt, int64_t R, float gscale, float* loss_out,
+                          float* dCr, void* stream);
+
+/* ---- a12: dense Adam / AdamW over a flat fp32 buffer -----------------------------------------
+ * torch.optim.Adam / AdamW single-tensor semantics (train_hash2.py:141-142): decoupled weight decay
+ * p *= 1-lr*wd (AdamW; wd = 0 for Adam), m,v EMA, bias correction with `step` (1-based),
+ * p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).  grad_scale multiplies g first (1/world_size after
+ * the all-reduce). */
+int hbr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
+                  void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HBR_HIP_H */
