@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Driver benchmark: ray-samples/s of a FULL hash-NeRF train step (fwd + bwd + optimiser) at 128 samples/ray
+on the synthetic lego-shaped scene (BASELINE.json metric; configs[1]: L=16, F=2, T=2^16, 16000 rays x 128 samples,
+bf16 MLP, fp32 tables).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: launched by torch.distributed.run, one rank per GPU; rays are sharded, 16000 rays PER RANK = weak scaling,
+     one RCCL all-reduce of the flat gradient buffer per step)
+
+Prints ONE JSON line on rank 0.  Inputs are resident in HBM before the timed region.  `roofline` is measured live
+with HIP events on the launch stream; `cpu_baseline` times the CPU oracle (oracle/ref_cpu.py, a port of the
+reference's PyTorch path) on a bounded sample on rank 0 at N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+# algorithmic work per ray-sample (DESIGN.md "Measurement")
+HASH_FWD_BYTES = 12 + 16 * 8 * 2 * 4 + 16 * 2 * 4   # x + 128 gathers of 8 B + y            = 1164 B
+HASH_BWD_BYTES = 12 + 16 * 2 * 4 + 16 * 8 * 2 * 4   # x + dy + 128 scatter-adds of 8 B      = 1164 B
+MLP_FWD_FLOP = 2 * (32 * 64 + 64 * 64 + 64 * 16 + 39 * 64 + 64 * 64 + 64 * 3)  # 27904
+MLP_BWD_FLOP = 3 * MLP_FWD_FLOP                     # recompute + data grad + weight grad
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--rays", type=int, default=16000, help="rays per rank per step (train_hash2.py:27)")
+    ap.add_argument("--samples", type=int, default=128)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--feat-dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import ref_cpu
+    from hbr_amd import _lib
+    from hbr_amd.trainer import HashNeRFTrainer, build_default_model
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+    assert _lib.lib().hbr_device_ok() == 1, "not a gfx950 device"
+
+    R, S = args.rays, args.samples
+    # ---- synthetic lego-shaped workload, resident in HBM ---------------------------------
+    # a pool of pre-shuffled ray batches per rank; the bbox comes from a fixed seed so every rank agrees on it
+    o0, d0, _, _ = ref_cpu.synthetic_rays(65536, seed=0)
+    mn, mx, sig = ref_cpu.bbox_mu_sigma(o0, d0, 2.0, 6.0)
+    pool = 8
+    batches = []
+    for b in range(pool):
+        o, d, dn, gt = ref_cpu.synthetic_rays(R, seed=1000 + rank * pool + b)
+        batches.append(tuple(a.to(dev).contiguous() for a in (o, d, dn.reshape(-1), gt)))
+    enc, denc, mlp = build_default_model(mn, sig, dev, seed=0)  # same init on every rank (replicated parameters)
+    prec = _lib.BF16 if args.precision == "bf16" else _lib.F32
+    fdt = _lib.BF16 if args.feat_dtype == "bf16" else _lib.F32
+    total_steps = 4000 * 1000  # train_hash2.py:156-157: epochs * len(loader) (1000 epochs x 4000 batches of the 64M lego rays)
+    tr = HashNeRFTrainer(enc, mlp, near=2.0, far=6.0, num_samples=S, total_steps=total_steps, precision=prec, feat_dtype=fdt)
+    torch.manual_seed(1234)  # identical jitter t[S] on every rank
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        tr.step(*batches[i % pool])
+    sync()
+    if not args.no_kernel_events:
+        tr.timers = {}
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        tr.step(*batches[i % pool])
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    loss = float(tr.last_loss.item())
+    samples = R * S * world * args.steps
+    value = samples / dt
+
+    # ---- per-kernel durations from the HIP events recorded on the launch stream --------------------------
+    kern = {}
+    if tr.timers:
+        for name, evs in tr.timers.items():
+            kern[name] = sum(a.elapsed_time(b) for a, b in evs) / len(evs)  # ms
+    N = R * S
+    roofs = {}
+    if kern:
+        roofs["hash_fwd"] = dict(bound="hbm", achieved=HASH_FWD_BYTES * N / (kern["hash_fwd"] * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+        roofs["hash_bwd"] = dict(bound="hbm", achieved=HASH_BWD_BYTES * N / (kern["hash_bwd"] * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+        roofs["mlp_fwd"] = dict(bound="mfma", achieved=MLP_FWD_FLOP * N / (kern["mlp_fwd"] * 1e-3) / 1e12, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s")
+        roofs["mlp_bwd"] = dict(bound="mfma", achieved=MLP_BWD_FLOP * N / (kern["mlp_bwd"] * 1e-3) / 1e12, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s")
+        pmc = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pmc = json.load(f)
+        except Exception:
+            pass
+        for k, r in roofs.items():
+            r["frac"] = r["achieved"] / r["peak"]
+            r["kernel"] = k
+            r["avg_ms"] = kern[k]
+            r["traffic"] = pmc.get(k)  # HBM bytes per launch from rocprofv3 --pmc passes (profiles/), or null
+    dominant = max(kern, key=kern.get) if kern else None
+
+    # ---- CPU baseline: the oracle (a port of the reference's PyTorch-CPU path) on a bounded sample ---------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import numpy as np
+        Rc = 256
+        ncores = os.cpu_count() or 1
+        torch.set_num_threads(ncores)
+        oc, dc, dnc, gtc = ref_cpu.synthetic_rays(Rc, seed=77)
+        rng = np.random.default_rng(0)
+        tabs = [torch.from_numpy(rng.uniform(-1e-4, 1e-4, (2 ** 16, 2)).astype(np.float32)).requires_grad_(True) for _ in range(16)]
+        prm = {k: v.requires_grad_(True) for k, v in ref_cpu.mlp_init(0).items()}
+        scales = ref_cpu.level_scales(16, 2048.0, 16)
+        opts = ref_cpu.make_optimizers(tabs, prm.values(), total_steps)
+        tc = ref_cpu.strat_jitter_to_t(2.0, 6.0, S, torch.rand(S))
+        ref_cpu.train_step((oc, dc, dnc, gtc), tc, tabs, scales, mn, sig, prm, opts)  # warm-up
+        n_it, c0 = 0, time.perf_counter()
+        while n_it < 3 or (time.perf_counter() - c0 < 10.0 and n_it < 50):
+            ref_cpu.train_step((oc, dc, dnc, gtc), tc, tabs, scales, mn, sig, prm, opts)
+            n_it += 1
+        cdt = time.perf_counter() - c0
+        cpu = dict(value=Rc * S * n_it / cdt, unit="ray-samples/s", cores=torch.get_num_threads(), kind="port",
+                   sample=f"{n_it} fp32 train steps of {Rc} rays x {S} samples (oracle/ref_cpu.py, torch CPU), same scene/config")
+
+    if rank == 0:
+        line = {
+            "metric": "ray-samples/sec @128 samples/ray on lego (full train step: fwd+bwd+optimiser)",
+            "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if prec == _lib.BF16 else "f32", "data": "synthetic",
+            "config": {"workload": "lego-shaped synthetic scene, hash encoding L=16 F=2 T=2^16 N_min=16 N_max=2048, "
+                                   f"{R} rays/rank x {S} samples/ray, MLP 32-64-64-16 / 39-64-64-3, fp32 tables, "
+                                   f"{'bf16' if prec == _lib.BF16 else 'fp32'} MLP (MFMA), Adam+AdamW+cosine",
+                       "rays_per_rank": R, "samples_per_ray": S, "global_rays": R * world, "levels": 16, "table_rows": 2 ** 16,
+                       "parallelism": f"ray-sharded dp{world}, 1 all-reduce/step" if world > 1 else "single GPU"},
+            "loss": loss,
+            "roofline": roofs.get(dominant), "roofline_hash_lookup": roofs.get("hash_fwd"), "kernels": roofs or None,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,57 @@
+"""Multi-GPU plumbing: one process per GPU, rays sharded, parameters replicated, ONE all-reduce per step.
+
+The reference's only parallelism is single-process torch.nn.DataParallel around the MLP (train_hash2.py:127); it is
+replaced, not reproduced.  The data path has no exchange step other than the gradient all-reduce:
+each rank renders R/P rays with its own replica, computes loss_p = mean over its shard, and
+grad = (1/P) * sum_p grad_p equals the single-process gradient of the mean over all R rays (equal shards).
+Backend "nccl" is RCCL on ROCm (xGMI between the 8 GPUs of a node); tests use "gloo" on CPU.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None, device: Optional[torch.device] = None) -> Tuple[int, int]:
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run sets
+    them).  Returns (rank, world).  No-op for world == 1."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world
+
+
+def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard [lo, hi) of n rays for `rank`; shards are equal-sized (n is truncated to a multiple of
+    world so every rank's mean-loss carries the same weight)."""
+    per = n // world
+    return rank * per, (rank + 1) * per
+
+
+def shard_batch(batch, rank: int, world: int):
+    lo, hi = shard_bounds(batch[0].shape[0], rank, world)
+    return tuple(b[lo:hi] for b in batch)
+
+
+def allreduce_mean_(flat: torch.Tensor, world: int, group=None, scale_in_place: bool = True) -> torch.Tensor:
+    """Sum `flat` over ranks (one collective over the single flat gradient buffer) and, unless the caller folds the
+    1/world factor into its optimiser kernel, scale it."""
+    if world > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if scale_in_place:
+            flat.mul_(1.0 / world)
+    return flat
+
+
+def broadcast_params_(tensors, src: int = 0, group=None) -> None:
+    """Make replicas identical at start-up (the reference relies on DataParallel's replicate each forward)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        for t in tensors:
+            dist.broadcast(t, src=src, group=group)

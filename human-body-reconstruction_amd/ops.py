@@ -90,6 +90,8 @@ def hash_encode_fwd(geom: HashGeom, tables: torch.Tensor, x: Optional[torch.Tens
             out = torch.zeros((N, L * F + extra_cols), dtype=tdt, device=tables.device) if extra_cols else \
                 torch.empty((N, L * F), dtype=tdt, device=tables.device)
     stride = out.shape[-1] if layout == ROWS else 0
+    if N == 0:
+        return out
     sc, mu = geom.c_args()
     check(lib().hbr_hash_encode_fwd(_ptr(x), _ptr(o), _ptr(d), _ptr(t), R, S, tables.data_ptr(), sc, mu, geom.sigma,
                                     L, geom.T, F, out.data_ptr(), layout, stride, dtype, _stream()), "hbr_hash_encode_fwd")
@@ -111,6 +113,8 @@ def hash_encode_bwd(geom: HashGeom, dy: torch.Tensor, dtables: torch.Tensor, x: 
         dy = dy.contiguous()
     dtype = F32 if dy.dtype == torch.float32 else BF16
     stride = dy.shape[-1] if layout == ROWS else 0
+    if R * S == 0:
+        return dtables
     sc, mu = geom.c_args()
     check(lib().hbr_hash_encode_bwd(_ptr(x), _ptr(o), _ptr(d), _ptr(t), R, S, dy.data_ptr(), layout, stride, dtype, sc, mu,
                                     geom.sigma, geom.L, geom.T, geom.F, dtables.data_ptr(), algo, None, 0, _stream()),
@@ -123,6 +127,8 @@ def dir_encode(x: torch.Tensor, num_freq: int) -> torch.Tensor:
     lead, d = x.shape[:-1], x.shape[-1]
     xf = _f32c(x).reshape(-1, d)
     out = torch.empty((xf.shape[0], d * 2 * num_freq), dtype=torch.float32, device=x.device)
+    if xf.shape[0] == 0:
+        return out.reshape(*lead, d * 2 * num_freq)
     check(lib().hbr_dir_encode(xf.data_ptr(), xf.shape[0], d, num_freq, out.data_ptr(), _stream()), "hbr_dir_encode")
     return out.reshape(*lead, d * 2 * num_freq)
 
@@ -143,6 +149,8 @@ def mlp_fwd(feat: torch.Tensor, layout: int, viewdirs_enc: torch.Tensor, group: 
     N, stride, dtype = _feat_desc(feat, layout)
     out = torch.empty((N, 4), dtype=torch.float32, device=feat.device)
     ws = _mlp_ws(precision, feat.device)
+    if N == 0:
+        return out
     check(lib().hbr_mlp_fwd(feat.data_ptr(), layout, stride, dtype, viewdirs_enc.data_ptr(), N, group, params.data_ptr(),
                             precision, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "hbr_mlp_fwd")
     return out
@@ -154,6 +162,8 @@ def mlp_bwd(feat: torch.Tensor, layout: int, viewdirs_enc: torch.Tensor, group: 
     dfeat = torch.empty_like(feat) if need_dfeat else None
     ws = _mlp_ws(precision, feat.device)
     dout = _f32c(dout)
+    if N == 0:
+        return dfeat
     check(lib().hbr_mlp_bwd(feat.data_ptr(), layout, stride, dtype, viewdirs_enc.data_ptr(), N, group, params.data_ptr(),
                             precision, dout.data_ptr(), _ptr(dfeat), dparams.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
           "hbr_mlp_bwd")

@@ -1,0 +1,145 @@
+"""The train_hash2.py loop (reference train_hash2.py:106-306) restated on the gfx950 pipeline.
+
+One `HashNeRFTrainer.step(batch)` = one iteration of the reference's loop body (:211-239):
+    t = strat_sampler(near, far, S)                       helper.py:234-235
+    Cr, Cf, _ = vol_render(..., hierarchical=False)       vol_renderer.py:141-245
+    loss = MSE(Cr, gt) + MSE(Cf, gt)                      train_hash2.py:177,221   (= 2*MSE, Cf is Cr)
+    loss.backward()                                       :226
+    Adam(lr .05) on the tables, AdamW(lr .005) on the MLP :141-142,227-228
+    cosine annealing of both learning rates               :156-162,231-232
+without going through autograd: forward kernels, the loss kernel, three backward kernels, one optional
+RCCL all-reduce of a single flat gradient buffer, two fused Adam launches.  bf16 needs no GradScaler.
+
+Multi-GPU: rays are sharded over ranks (one process per GPU), parameters are replicated, and
+the only collective is ONE all-reduce(sum) per step over [d tables | d MLP] (8.05 MiB fp32); the 1/world
+factor is folded into the Adam kernel's grad_scale.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from . import ops
+from ._lib import BF16, F32, MLP_PARAM_FLOATS, PLANAR
+from .encoder import PositionalEncoder
+from .hash_encoding import HashEncoder
+from .helper import strat_sampler
+from .test_hash import MLP_3D
+
+
+def cosine_lr(base_lr: float, eta_min: float, step: int, t_max: int) -> float:
+    """torch.optim.lr_scheduler.CosineAnnealingLR in closed form (lr used by optimiser step `step`, 0-based)."""
+    return eta_min + (base_lr - eta_min) * (1.0 + math.cos(math.pi * step / t_max)) / 2.0
+
+
+class HashNeRFTrainer:
+    def __init__(self, encoder: HashEncoder, mlp: MLP_3D, near: float = 2.0, far: float = 6.0, num_samples: int = 128,
+                 total_steps: int = 100000, lr_embed: float = 0.05, lr_mlp: float = 0.005, eta_min: float = 1e-4,
+                 weight_decay_mlp: float = 0.01, precision: int = BF16, feat_dtype: int = F32, num_freq: int = 4,
+                 process_group=None, scatter_algo: int = 0):
+        self.enc, self.mlp = encoder, mlp
+        self.near, self.far, self.S = float(near), float(far), int(num_samples)
+        self.total_steps = int(total_steps)
+        self.lr_embed, self.lr_mlp, self.eta_min, self.wd_mlp = lr_embed, lr_mlp, eta_min, weight_decay_mlp
+        self.precision, self.feat_dtype, self.num_freq = precision, feat_dtype, num_freq
+        self.scatter_algo = scatter_algo
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+        self.tables = encoder.stacked_tables()
+        self.flat, self.splits = mlp.flat_params()
+        dev = self.tables.device
+        self.geom = encoder.geometry()
+        self.n_tab = self.tables.numel()
+        n = self.n_tab + MLP_PARAM_FLOATS
+        n_pad = (n + 3) // 4 * 4
+        self.grad = torch.zeros(n_pad, dtype=torch.float32, device=dev)       # [d tables | d MLP | pad]
+        self.m = torch.zeros(n_pad, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n_pad, dtype=torch.float32, device=dev)
+        self.g_tab = self.grad[:self.n_tab].view_as(self.tables)
+        self.g_mlp = self.grad[self.n_tab:self.n_tab + MLP_PARAM_FLOATS]
+        self.step_count = 0
+        self.last_loss = None
+        self.timers = None  # optional dict name -> list[(start_event, end_event)], filled when set by bench.py
+
+    # ---- helpers ------------------------------------------------------------------------------
+    def _timed(self, name, fn):
+        if self.timers is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        self.timers.setdefault(name, []).append((e0, e1))
+        return r
+
+    def sample_t(self, device) -> torch.Tensor:
+        return strat_sampler(self.near, self.far, self.S, device=device)
+
+    # ---- one optimisation step ------------------------------------------------------------------
+    def step(self, rays_o, rays_d, dir_norm, gt, t: Optional[torch.Tensor] = None):
+        """rays_o/rays_d [R,3], dir_norm [R,1] or [R], gt [R,3], all resident on the GPU."""
+        S, g = self.S, self.geom
+        R = rays_o.shape[0]
+        if t is None:
+            t = self.sample_t(rays_o.device)
+        dn = dir_norm.reshape(-1) if torch.is_tensor(dir_norm) else None
+        rays = (rays_o, rays_d, t)
+        # forward
+        pe = ops.dir_encode(rays_d, self.num_freq)
+        feat = self._timed("hash_fwd", lambda: ops.hash_encode_fwd(g, self.tables, rays=rays, layout=PLANAR, dtype=self.feat_dtype))
+        out = self._timed("mlp_fwd", lambda: ops.mlp_fwd(feat, PLANAR, pe, S, self.flat, self.precision))
+        Cr, _ = ops.composite_fwd(t, out.data_ptr(), 4, out.data_ptr() + 12, 4, dn, R, S, want_wts=False)
+        # loss + backward
+        loss, dCr = ops.mse2_loss(Cr, gt)
+        d_out = torch.empty_like(out)
+        ops.composite_bwd(t, out.data_ptr(), 4, out.data_ptr() + 12, 4, dn, R, S, dCr, d_out.data_ptr(), d_out.data_ptr() + 12)
+        self.grad.zero_()
+        dfeat = self._timed("mlp_bwd", lambda: ops.mlp_bwd(feat, PLANAR, pe, S, self.flat, self.precision, d_out, self.g_mlp))
+        self._timed("hash_bwd", lambda: ops.hash_encode_bwd(g, dfeat, self.g_tab, rays=rays, layout=PLANAR, algo=self.scatter_algo))
+        # the one collective of the step
+        if self.world > 1:
+            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        # optimiser (dense Adam over every table row, as the reference's torch.optim.Adam does)
+        k = self.step_count
+        gs = 1.0 / self.world
+        nt = self.n_tab
+        ops.adam_step(self.tables.view(-1), self.grad[:nt], self.m[:nt], self.v[:nt],
+                      cosine_lr(self.lr_embed, self.eta_min, k, self.total_steps), 0.9, 0.999, 1e-8, 0.0, k + 1, gs)
+        ops.adam_step(self.flat, self.g_mlp, self.m[nt:nt + MLP_PARAM_FLOATS], self.v[nt:nt + MLP_PARAM_FLOATS],
+                      cosine_lr(self.lr_mlp, self.eta_min, k, self.total_steps), 0.9, 0.999, 1e-8, self.wd_mlp, k + 1, gs)
+        self.step_count += 1
+        self.last_loss = loss
+        return loss
+
+    # ---- inference ------------------------------------------------------------------------------
+    @torch.no_grad()
+    def render(self, rays_o, rays_d, dir_norm, num_samples: Optional[int] = None, t: Optional[torch.Tensor] = None, chunk: int = 16000):
+        """Image-write path (train_hash2.py:277-292): 16000-ray chunks, unmasked branch."""
+        S = num_samples or self.S
+        if t is None:
+            t = strat_sampler(self.near, self.far, S, device=rays_o.device)
+        outs = []
+        for i in range(0, rays_o.shape[0], chunk):
+            o, d = rays_o[i:i + chunk].contiguous(), rays_d[i:i + chunk].contiguous()
+            dn = dir_norm[i:i + chunk].reshape(-1).contiguous() if torch.is_tensor(dir_norm) else None
+            pe = ops.dir_encode(d, self.num_freq)
+            feat = ops.hash_encode_fwd(self.geom, self.tables, rays=(o, d, t), layout=PLANAR, dtype=self.feat_dtype)
+            out = ops.mlp_fwd(feat, PLANAR, pe, t.shape[0], self.flat, self.precision)
+            Cr, _ = ops.composite_fwd(t, out.data_ptr(), 4, out.data_ptr() + 12, 4, dn, o.shape[0], t.shape[0], want_wts=False)
+            outs.append(Cr)
+        return torch.cat(outs)
+
+
+def build_default_model(mu: torch.Tensor, sigma: torch.Tensor, device, L: int = 16, F: int = 2, T: int = 2 ** 16,
+                        N_min=16, N_max=2048.0, num_freq: int = 4, seed: Optional[int] = None):
+    """The objects train_hash2.py:120-127 builds (encoder, direction encoder, MLP)."""
+    if seed is not None:
+        torch.manual_seed(seed)
+    enc = HashEncoder(N_min=N_min, N_max=N_max, L=L, F=F, T=T, dim=3, mu=mu.to(device), sigma=sigma.to(device), device=device)
+    denc = PositionalEncoder(d_model=3, num_freq=num_freq)
+    mlp = MLP_3D(num_sig=2, num_col=2, L=L, F=F, d_view=3 * num_freq * 2).to(device)
+    return enc, denc, mlp
