@@ -86,6 +86,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    print(f"[bench] rank {rank}/{world}: model + {pool} batches resident, warming up", file=sys.stderr, flush=True)
     for i in range(args.warmup):
         tr.step(*batches[i % pool])
     sync()
@@ -100,6 +101,7 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
+    print(f"[bench] timed {args.steps} steps in {dt:.3f}s", file=sys.stderr, flush=True)
     loss = float(tr.last_loss.item())
     samples = R * S * world * args.steps
     value = samples / dt
@@ -134,8 +136,14 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import numpy as np
         Rc = 256
-        ncores = os.cpu_count() or 1
+        # the box's CPU share, not os.cpu_count(): oversubscribing a cgroup-limited host stalls torch's thread pool
+        try:
+            ncores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            ncores = os.cpu_count() or 1
+        ncores = max(1, min(ncores, 16))
         torch.set_num_threads(ncores)
+        print(f"[bench] cpu baseline on {ncores} threads ...", file=sys.stderr, flush=True)
         oc, dc, dnc, gtc = ref_cpu.synthetic_rays(Rc, seed=77)
         rng = np.random.default_rng(0)
         tabs = [torch.from_numpy(rng.uniform(-1e-4, 1e-4, (2 ** 16, 2)).astype(np.float32)).requires_grad_(True) for _ in range(16)]
@@ -145,7 +153,7 @@ def main():
         tc = ref_cpu.strat_jitter_to_t(2.0, 6.0, S, torch.rand(S))
         ref_cpu.train_step((oc, dc, dnc, gtc), tc, tabs, scales, mn, sig, prm, opts)  # warm-up
         n_it, c0 = 0, time.perf_counter()
-        while n_it < 3 or (time.perf_counter() - c0 < 10.0 and n_it < 50):
+        while (n_it < 3 and time.perf_counter() - c0 < 60.0) or (time.perf_counter() - c0 < 10.0 and n_it < 50):
             ref_cpu.train_step((oc, dc, dnc, gtc), tc, tabs, scales, mn, sig, prm, opts)
             n_it += 1
         cdt = time.perf_counter() - c0
