@@ -6,7 +6,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhbr_hip.so")
+# HBR_LIB overrides the library path (A/B timing of ablation builds only)
+LIB_PATH = os.environ.get("HBR_LIB") or os.path.join(_HERE, "libhbr_hip.so")
 
 ROWS, PLANAR = 0, 1
 F32, BF16 = 0, 1

@@ -8,10 +8,12 @@
 // only; results do not depend on it.
 //
 // Backward: (algo 1) one float atomic per corner-feature; (algo 2) a workgroup owns one
-// 16384-row slice of one level in LDS (128 KiB), sweeps a chunk of the points, accumulates the
-// corners that fall into its slice with LDS atomics and flushes the slice once with contiguous
-// 256-B global atomics (MI355X_MICROARCH "Global float atomics": contiguous atomics run 17x the
-// one-row-per-lane rate).
+// 8192-row slice of one level in LDS as fp64 accumulators (128 KiB), sweeps a chunk of the points,
+// accumulates the corners that fall into its slice with ds_add_f64 and flushes the slice once with
+// contiguous 256-B global float atomics (MI355X_MICROARCH "Global float atomics": contiguous atomics
+// run 17x the one-row-per-lane rate).  fp64 because on gfx950 ds_add_f32 costs ~190 cycles per
+// wave-instruction while ds_add_f64 costs ~21 (measured: tools/lds_atomic_bench.hip); as a bonus the
+// 53-bit sums make the result independent of arrival order to well below one fp32 ulp.
 #include "hbr_common.h"
 
 namespace hbr {
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(kFwdThreads) void hash_bwd_atomic_kernel(PointSrc p
 // ------------------------------------------------------------------------------------------------
 // K2 backward, algo 2: LDS-resident table slice per workgroup
 // ------------------------------------------------------------------------------------------------
-constexpr int kSliceLog2 = 14;                 // 16384 rows * 2 floats * 4 B = 128 KiB of the CU's 160 KiB LDS
+constexpr int kSliceLog2 = 13;                 // 8192 rows * 2 doubles * 8 B = 128 KiB of the CU's 160 KiB LDS
 constexpr int kSliceRows = 1 << kSliceLog2;
 constexpr int kLdsBwdThreads = 1024;
 
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(kLdsBwdThreads) void hash_bwd_lds_kernel(PointSrc p
                                                                       int64_t dy_stride, HashGeom g,
                                                                       float* __restrict__ dtables, int slices_per_level,
                                                                       int chunks) {
-  extern __shared__ float acc[];  // [kSliceRows][2]
+  extern __shared__ double acc[];  // [kSliceRows][2]
   // block -> (level, slice, chunk); chunk varies fastest so the blocks of one (level, slice) start together
   const uint32_t b = blockIdx.x;
   const uint32_t chunk = b % chunks;
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(kLdsBwdThreads) void hash_bwd_lds_kernel(PointSrc p
   const uint32_t slice = ls % slices_per_level;
   const int l = ls / slices_per_level;
 
-  for (int i = threadIdx.x; i < kSliceRows * 2; i += kLdsBwdThreads) acc[i] = 0.f;
+  for (int i = threadIdx.x; i < kSliceRows * 2; i += kLdsBwdThreads) acc[i] = 0.0;
   __syncthreads();
 
   const uint32_t row_lo = slice << kSliceLog2;
@@ -174,8 +176,12 @@ __global__ __launch_bounds__(kLdsBwdThreads) void hash_bwd_lds_kernel(PointSrc p
     for (int k = 0; k < 8; ++k) {
       uint32_t rel = rows[k] - row_lo;  // wraps to a huge value when the row is below the slice
       if (rel < (uint32_t)kSliceRows) {
-        atomicAdd(&acc[rel * 2 + 0], __fmul_rn(w[k], d0));
-        atomicAdd(&acc[rel * 2 + 1], __fmul_rn(w[k], d1));
+#ifdef HBR_ABL_NO_DSADD
+        asm volatile("" ::"v"(rel), "v"(__fmul_rn(w[k], d0)), "v"(__fmul_rn(w[k], d1)));
+#else
+        atomicAdd(&acc[rel * 2 + 0], (double)__fmul_rn(w[k], d0));
+        atomicAdd(&acc[rel * 2 + 1], (double)__fmul_rn(w[k], d1));
+#endif
       }
     }
   }
@@ -185,7 +191,7 @@ __global__ __launch_bounds__(kLdsBwdThreads) void hash_bwd_lds_kernel(PointSrc p
   const int64_t rows_here = min((int64_t)kSliceRows, g.T - (int64_t)row_lo);
   float* out = dtables + ((size_t)l * g.T + row_lo) * 2;
   for (int64_t i = threadIdx.x; i < rows_here * 2; i += kLdsBwdThreads) {
-    float v = acc[i];
+    const float v = (float)acc[i];
     if (v != 0.f) unsafeAtomicAdd(out + i, v);
   }
 }
@@ -218,10 +224,10 @@ static void launch_bwd(int algo, hipStream_t st, PointSrc ps, uint32_t N, const 
     static bool attr_set[2][2][2] = {};
     auto kern = hash_bwd_lds_kernel<POW2, LAYOUT, DTYPE>;
     if (!attr_set[POW2][LAYOUT][DTYPE]) {
-      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kSliceRows * 2 * sizeof(float));
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kSliceRows * 2 * sizeof(double));
       attr_set[POW2][LAYOUT][DTYPE] = true;
     }
-    hipLaunchKernelGGL(kern, dim3((uint32_t)(g.L * spl * chunks)), dim3(kLdsBwdThreads), kSliceRows * 2 * sizeof(float), st, ps, N,
+    hipLaunchKernelGGL(kern, dim3((uint32_t)(g.L * spl * chunks)), dim3(kLdsBwdThreads), kSliceRows * 2 * sizeof(double), st, ps, N,
                        dy, stride, g, dtables, spl, chunks);
   }
 }

@@ -207,29 +207,39 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ par
 // ------------------------------------------------------------------------------------------------
 // device building blocks
 // ------------------------------------------------------------------------------------------------
+// `lofs` = lane * sizeof(frag), laundered through an empty asm once per point tile (opaque_lane_offset) so the
+// compiler cannot prove the weight loads loop-invariant: hoisting all ~62 fragments (250 registers) out of the tile
+// loop is what it does otherwise, and the kernel then spills.
 template <class P>
-__device__ __forceinline__ typename P::frag ldw(const char* img, int fid, int lane) {
-  return ((const typename P::frag*)img)[fid * 64 + lane];
+__device__ __forceinline__ typename P::frag ldw(const char* img, int fid, int lofs) {
+  return *(const typename P::frag*)(img + fid * 64 * (int)sizeof(typename P::frag) + lofs);
+}
+template <class P>
+__device__ __forceinline__ int opaque_lane_offset(int lane) {
+  int v = lane * (int)sizeof(typename P::frag);
+  asm volatile("" : "+v"(v));
+  return v;
 }
 
 // acc[m] = bias ; acc[m] += sum_ks W_frag(m,ks) * x[ks]      (orientation 1)
 template <class P, int NOUT, int NK, bool BIAS>
-__device__ __forceinline__ void dense(const char* img, int fbase, const float* bias, int lane, const typename P::frag (&x)[NK],
-                                      f32x16 (&acc)[NOUT]) {
+__device__ __forceinline__ void dense(const char* img, int fbase, const float* bias, int lane, int lofs,
+                                      const typename P::frag (&x)[NK], f32x16 (&acc)[NOUT]) {
   const int h = lane >> 5;
+  const int bofs = lofs - lane * (int)sizeof(typename P::frag);  // opaque zero: keeps the bias loads inside the loop too
 #pragma unroll
   for (int m = 0; m < NOUT; ++m) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (BIAS) b = *(const float4*)(bias + 32 * m + 8 * g + 4 * h);
+      if (BIAS) b = *(const float4*)((const char*)bias + bofs + 4 * (32 * m + 8 * g + 4 * h));
       acc[m][4 * g + 0] = b.x; acc[m][4 * g + 1] = b.y; acc[m][4 * g + 2] = b.z; acc[m][4 * g + 3] = b.w;
     }
   }
 #pragma unroll
   for (int m = 0; m < NOUT; ++m) {
 #pragma unroll
-    for (int ks = 0; ks < NK; ++ks) acc[m] = P::mfma(ldw<P>(img, fbase + m * NK + ks, lane), x[ks], acc[m]);
+    for (int ks = 0; ks < NK; ++ks) acc[m] = P::mfma(ldw<P>(img, fbase + m * NK + ks, lofs), x[ks], acc[m]);
   }
 }
 
@@ -326,6 +336,7 @@ __device__ __forceinline__ void forward_tile(const char* img, const float* bias,
                                              bool valid, int lane, Saved<P>& sv) {
   using T = Tab<P>;
   const int h = lane >> 5;
+  const int lofs = opaque_lane_offset<P>(lane);
   load_feat_frags<P, LAYOUT, DT>(fs, n, valid, h, sv.x0);
   float4 peA = make_float4(0, 0, 0, 0), peB = peA, peC = peA;
   if (valid) {
@@ -336,33 +347,33 @@ __device__ __forceinline__ void forward_tile(const char* img, const float* bias,
   }
   {
     f32x16 a[2];
-    dense<P, 2, P::S32, true>(img, T::f_base(L1), bias + 64 * L1, lane, sv.x0, a);
+    dense<P, 2, P::S32, true>(img, T::f_base(L1), bias + 64 * L1, lane, lofs, sv.x0, a);
     relu_frags<P, 2>(a, sv.m1, sv.h1);
   }
   {
     f32x16 a[2];
-    dense<P, 2, 2 * P::S32, true>(img, T::f_base(L2), bias + 64 * L2, lane, sv.h1, a);
+    dense<P, 2, 2 * P::S32, true>(img, T::f_base(L2), bias + 64 * L2, lane, lofs, sv.h1, a);
     relu_frags<P, 2>(a, sv.m2, sv.h2);
   }
   {
     f32x16 a[1];
-    dense<P, 1, 2 * P::S32, true>(img, T::f_base(L3), bias + 64 * L3, lane, sv.h2, a);
+    dense<P, 1, 2 * P::S32, true>(img, T::f_base(L3), bias + 64 * L3, lane, lofs, sv.h2, a);
     sv.s0 = a[0][0];
     P::cin(a[0], peA, peB, peC, sv.cin);
   }
   {
     f32x16 a[2];
-    dense<P, 2, P::S32 + P::S8, true>(img, T::f_base(C1), bias + 64 * C1, lane, sv.cin, a);
+    dense<P, 2, P::S32 + P::S8, true>(img, T::f_base(C1), bias + 64 * C1, lane, lofs, sv.cin, a);
     relu_frags<P, 2>(a, sv.mc1, sv.c1);
   }
   {
     f32x16 a[2];
-    dense<P, 2, 2 * P::S32, true>(img, T::f_base(C2), bias + 64 * C2, lane, sv.c1, a);
+    dense<P, 2, 2 * P::S32, true>(img, T::f_base(C2), bias + 64 * C2, lane, lofs, sv.c1, a);
     relu_frags<P, 2>(a, sv.mc2, sv.c2);
   }
   {
     f32x16 a[1];
-    dense<P, 1, 2 * P::S32, true>(img, T::f_base(C3), bias + 64 * C3, lane, sv.c2, a);
+    dense<P, 1, 2 * P::S32, true>(img, T::f_base(C3), bias + 64 * C3, lane, lofs, sv.c2, a);
     sv.raw[0] = a[0][0]; sv.raw[1] = a[0][1]; sv.raw[2] = a[0][2];
   }
 }
@@ -407,6 +418,10 @@ __global__ __launch_bounds__(kFwdWaves * 64) void mlp_fwd_kernel(const char* __r
 // backward kernel
 // ------------------------------------------------------------------------------------------------
 constexpr int kDwTiles = 18;  // L1:2 L2:4 L3:2 C1:4 C2:4 C3:2
+#ifndef HBR_BWD_PART_A
+#define HBR_BWD_PART_A 1  // bf16: 1 = two launches (density net + d feat / colour net): 410 / 428 registers, no spills;
+                          //       0 = one launch with all 18 dW tiles resident (spills 532 B/lane with hipcc 7.2)
+#endif
 __device__ __host__ constexpr int dw_tile_base(int l) {
   constexpr int b[NLAYER] = {0, 2, 6, 8, 12, 16};
   return b[l];
@@ -431,27 +446,35 @@ __device__ __forceinline__ void transpose_frags(const typename P::frag (&x)[NK],
   }
 }
 
-// dW^T tiles of one layer: [in tile n][out tile m] += XT[n] (A, k = points) x dZT[m] (B); bias grads from dZT
-template <class P, int NIN, int NOUT>
-__device__ __forceinline__ void wgrad(float* dw, float* db, int layer, int lane, const typename P::frag (&xt)[NIN][P::S32],
+// Persistent per-wave weight-gradient accumulators.  LDS float atomics (ds_add_f32) cost ~190 cycles per
+// wave-instruction on gfx950 (measured, tools/lds_atomic_bench.hip; ds_add_u32 ~7, ds_add_f64 ~21), so the dW tiles
+// are NOT accumulated in LDS per point tile: each wave keeps its dW^T tiles in registers across its whole sweep of
+// point tiles (the wgrad MFMA accumulates straight into them) and adds them to the workgroup's LDS image once.
+struct DwAcc {
+  f32x16 t[kDwTiles];
+  float b[10];  // bias grads: L1:0,1 L2:2,3 L3:4 C1:5,6 C2:7,8 C3:9
+};
+__device__ __host__ constexpr int db_base(int l) {
+  constexpr int b[NLAYER] = {0, 2, 4, 5, 7, 9};
+  return b[l];
+}
+
+// dW^T tiles of one layer: [in tile n][out tile m] += XT[n] (A, k = points) x dZT[m] (B)
+template <class P, int LAYER, int NIN, int NOUT>
+__device__ __forceinline__ void wgrad(DwAcc& A, const typename P::frag (&xt)[NIN][P::S32],
                                       const typename P::frag (&dzt)[NOUT][P::S32]) {
 #pragma unroll
   for (int n = 0; n < NIN; ++n) {
 #pragma unroll
     for (int m = 0; m < NOUT; ++m) {
-      f32x16 acc;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-#pragma unroll
-      for (int s = 0; s < P::S32; ++s) acc = P::mfma(xt[n][s], dzt[m][s], acc);
-      float* t = dw + ((dw_tile_base(layer) + n * NOUT + m) * 16) * 64 + lane;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) atomicAdd(t + q * 64, acc[q]);
+      for (int s = 0; s < P::S32; ++s)
+        A.t[dw_tile_base(LAYER) + n * NOUT + m] = P::mfma(xt[n][s], dzt[m][s], A.t[dw_tile_base(LAYER) + n * NOUT + m]);
     }
   }
 }
 
-// bias gradient: sum of the orientation-2 dZ tile over its 16 point registers (two lane halves add up in LDS)
+// bias gradient: sum of the orientation-2 dZ tile over its 16 point registers (the two lane halves meet in LDS)
 template <class P>
 __device__ __forceinline__ float frag_sum(const typename P::frag (&f)[P::S32]) {
   float s = 0.f;
@@ -467,10 +490,10 @@ __device__ __forceinline__ float frag_sum(const typename P::frag (&f)[P::S32]) {
   return s;
 }
 
-template <class P, int NOUT>
-__device__ __forceinline__ void bgrad(float* db, int layer, int lane, const typename P::frag (&dzt)[NOUT][P::S32]) {
+template <class P, int LAYER, int NOUT>
+__device__ __forceinline__ void bgrad(DwAcc& A, const typename P::frag (&dzt)[NOUT][P::S32]) {
 #pragma unroll
-  for (int m = 0; m < NOUT; ++m) atomicAdd(db + layer * 64 + 32 * m + (lane & 31), frag_sum<P>(dzt[m]));
+  for (int m = 0; m < NOUT; ++m) A.b[db_base(LAYER) + m] += frag_sum<P>(dzt[m]);
 }
 
 struct DFeatDst {
@@ -478,7 +501,9 @@ struct DFeatDst {
   int64_t stride;
 };
 
-template <class P, int LAYOUT, int DT, int NWAVES, bool WLDS>
+// PART selects which layers' weight gradients this launch produces (their accumulators live in registers):
+//   0 = all six layers, 1 = density net (L1..L3) + d feat, 2 = colour net (C1..C3) only (no L3..L1 back-propagation).
+template <class P, int LAYOUT, int DT, int NWAVES, bool WLDS, int PART>
 __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(const char* __restrict__ gimg, FeatSrc fs, PeSrc ps,
                                                               const float* __restrict__ dout, DFeatDst dfd,
                                                               float* __restrict__ dparams) {
@@ -494,12 +519,21 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(const char* __rest
   const float* bias = (const float*)(img + T::BIAS_OFF_ALL);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5;
   const uint32_t ntiles = (fs.N + 31) / 32;
+  constexpr bool kSig = PART != 2, kCol = PART != 1;
+  DwAcc A;
+#pragma unroll
+  for (int i = 0; i < kDwTiles; ++i)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) A.t[i][q] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) A.b[i] = 0.f;
 
   for (uint32_t tile = blockIdx.x * NWAVES + wv; tile < ntiles; tile += gridDim.x * NWAVES) {
     const uint32_t n = tile * 32 + (lane & 31);
     const bool valid = n < fs.N;
     Saved<P> sv;
     forward_tile<P, LAYOUT, DT>(img, bias, fs, ps, n, valid, lane, sv);
+    const int lofs = opaque_lane_offset<P>(lane);
     float4 dO = make_float4(0.f, 0.f, 0.f, 0.f);
     if (valid && h == 0) dO = ((const float4*)dout)[n];
 
@@ -515,103 +549,129 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(const char* __rest
 #pragma unroll
       for (int s = 0; s < P::S8; ++s) dz3[s] = P::from_acc(a, s);
     }
-    {
+    if (kCol) {
       typename P::frag xt[2][P::S32], zt[1][P::S32];
       transpose_frags<P, 2, 2 * P::S32>(sv.c2, lane, xt);
       transpose_frags<P, 1, P::S8>(dz3, lane, zt);
-      wgrad<P, 2, 1>(dw, db, C3, lane, xt, zt);
-      bgrad<P, 1>(db, C3, lane, zt);
+      wgrad<P, C3, 2, 1>(A, xt, zt);
+      bgrad<P, C3, 1>(A, zt);
     }
     // ---- C2
     typename P::frag dzc2[2 * P::S32];
     {
       f32x16 a[2];
-      dense<P, 2, P::S8, false>(img, T::b_base(C3), nullptr, lane, dz3, a);
+      dense<P, 2, P::S8, false>(img, T::b_base(C3), nullptr, lane, lofs, dz3, a);
       mask_frags<P, 2>(a, sv.mc2, dzc2);
-      typename P::frag xt[2][P::S32], zt[2][P::S32];
-      transpose_frags<P, 2, 2 * P::S32>(sv.c1, lane, xt);
-      transpose_frags<P, 2, 2 * P::S32>(dzc2, lane, zt);
-      wgrad<P, 2, 2>(dw, db, C2, lane, xt, zt);
-      bgrad<P, 2>(db, C2, lane, zt);
+      if (kCol) {
+        typename P::frag xt[2][P::S32], zt[2][P::S32];
+        transpose_frags<P, 2, 2 * P::S32>(sv.c1, lane, xt);
+        transpose_frags<P, 2, 2 * P::S32>(dzc2, lane, zt);
+        wgrad<P, C2, 2, 2>(A, xt, zt);
+        bgrad<P, C2, 2>(A, zt);
+      }
     }
     // ---- C1
     typename P::frag dzc1[2 * P::S32];
     {
       f32x16 a[2];
-      dense<P, 2, 2 * P::S32, false>(img, T::b_base(C2), nullptr, lane, dzc2, a);
+      dense<P, 2, 2 * P::S32, false>(img, T::b_base(C2), nullptr, lane, lofs, dzc2, a);
       mask_frags<P, 2>(a, sv.mc1, dzc1);
-      typename P::frag xt[2][P::S32], zt[2][P::S32];
-      transpose_frags<P, 2, P::S32 + P::S8>(sv.cin, lane, xt);
-      transpose_frags<P, 2, 2 * P::S32>(dzc1, lane, zt);
-      wgrad<P, 2, 2>(dw, db, C1, lane, xt, zt);
-      bgrad<P, 2>(db, C1, lane, zt);
+      if (kCol) {
+        typename P::frag xt[2][P::S32], zt[2][P::S32];
+        transpose_frags<P, 2, P::S32 + P::S8>(sv.cin, lane, xt);
+        transpose_frags<P, 2, 2 * P::S32>(dzc1, lane, zt);
+        wgrad<P, C1, 2, 2>(A, xt, zt);
+        bgrad<P, C1, 2>(A, zt);
+      }
     }
-    // ---- L3: ds rows 1..15 = d cin slots 1..15 ; row 0 = d sigma * lrelu'(s0)
-    typename P::frag dz_s[P::S16];
-    {
-      f32x16 a[1];
-      dense<P, 1, 2 * P::S32, false>(img, T::b_base(C1), nullptr, lane, dzc1, a);
-      if (h == 0) a[0][0] = dO.w * (sv.s0 > 0.f ? 1.f : 0.01f);
+    if (kSig) {
+      // ---- L3: ds rows 1..15 = d cin slots 1..15 ; row 0 = d sigma * lrelu'(s0)
+      typename P::frag dz_s[P::S16];
+      {
+        f32x16 a[1];
+        dense<P, 1, 2 * P::S32, false>(img, T::b_base(C1), nullptr, lane, lofs, dzc1, a);
+        if (h == 0) a[0][0] = dO.w * (sv.s0 > 0.f ? 1.f : 0.01f);
 #pragma unroll
-      for (int s = 0; s < P::S16; ++s) dz_s[s] = P::from_acc(a[0], s);
-      typename P::frag xt[2][P::S32], zt[1][P::S32];
-      transpose_frags<P, 2, 2 * P::S32>(sv.h2, lane, xt);
-      transpose_frags<P, 1, P::S16>(dz_s, lane, zt);
-      wgrad<P, 2, 1>(dw, db, L3, lane, xt, zt);
-      bgrad<P, 1>(db, L3, lane, zt);
-    }
-    // ---- L2
-    typename P::frag dz2[2 * P::S32];
-    {
-      f32x16 a[2];
-      dense<P, 2, P::S16, false>(img, T::b_base(L3), nullptr, lane, dz_s, a);
-      mask_frags<P, 2>(a, sv.m2, dz2);
-      typename P::frag xt[2][P::S32], zt[2][P::S32];
-      transpose_frags<P, 2, 2 * P::S32>(sv.h1, lane, xt);
-      transpose_frags<P, 2, 2 * P::S32>(dz2, lane, zt);
-      wgrad<P, 2, 2>(dw, db, L2, lane, xt, zt);
-      bgrad<P, 2>(db, L2, lane, zt);
-    }
-    // ---- L1
-    typename P::frag dz1[2 * P::S32];
-    {
-      f32x16 a[2];
-      dense<P, 2, 2 * P::S32, false>(img, T::b_base(L2), nullptr, lane, dz2, a);
-      mask_frags<P, 2>(a, sv.m1, dz1);
-      typename P::frag xt[1][P::S32], zt[2][P::S32];
-      transpose_frags<P, 1, P::S32>(sv.x0, lane, xt);
-      transpose_frags<P, 2, 2 * P::S32>(dz1, lane, zt);
-      wgrad<P, 1, 2>(dw, db, L1, lane, xt, zt);
-      bgrad<P, 2>(db, L1, lane, zt);
-    }
-    // ---- d feat
-    if (dfd.p) {
-      f32x16 a[1];
-      dense<P, 1, 2 * P::S32, false>(img, T::b_base(L1), nullptr, lane, dz1, a);
-      if (valid) {
+        for (int s = 0; s < P::S16; ++s) dz_s[s] = P::from_acc(a[0], s);
+        typename P::frag xt[2][P::S32], zt[1][P::S32];
+        transpose_frags<P, 2, 2 * P::S32>(sv.h2, lane, xt);
+        transpose_frags<P, 1, P::S16>(dz_s, lane, zt);
+        wgrad<P, L3, 2, 1>(A, xt, zt);
+        bgrad<P, L3, 1>(A, zt);
+      }
+      // ---- L2
+      typename P::frag dz2[2 * P::S32];
+      {
+        f32x16 a[2];
+        dense<P, 2, P::S16, false>(img, T::b_base(L3), nullptr, lane, lofs, dz_s, a);
+        mask_frags<P, 2>(a, sv.m2, dz2);
+        typename P::frag xt[2][P::S32], zt[2][P::S32];
+        transpose_frags<P, 2, 2 * P::S32>(sv.h1, lane, xt);
+        transpose_frags<P, 2, 2 * P::S32>(dz2, lane, zt);
+        wgrad<P, L2, 2, 2>(A, xt, zt);
+        bgrad<P, L2, 2>(A, zt);
+      }
+      // ---- L1
+      typename P::frag dz1[2 * P::S32];
+      {
+        f32x16 a[2];
+        dense<P, 2, 2 * P::S32, false>(img, T::b_base(L2), nullptr, lane, lofs, dz2, a);
+        mask_frags<P, 2>(a, sv.m1, dz1);
+        typename P::frag xt[1][P::S32], zt[2][P::S32];
+        transpose_frags<P, 1, P::S32>(sv.x0, lane, xt);
+        transpose_frags<P, 2, 2 * P::S32>(dz1, lane, zt);
+        wgrad<P, L1, 1, 2>(A, xt, zt);
+        bgrad<P, L1, 2>(A, zt);
+      }
+      // ---- d feat
+      if (dfd.p) {
+        f32x16 a[1];
+        dense<P, 1, 2 * P::S32, false>(img, T::b_base(L1), nullptr, lane, lofs, dz1, a);
+        if (valid) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          // registers 4g..4g+3 <-> features 8g+4h .. 8g+4h+3 = levels 4g+2h, 4g+2h+1
-          const float v0 = a[0][4 * g], v1 = a[0][4 * g + 1], v2 = a[0][4 * g + 2], v3 = a[0][4 * g + 3];
-          const int lvl = 4 * g + 2 * h;
-          if (LAYOUT == HBR_LAYOUT_PLANAR) {
-            if (DT == HBR_F32) {
-              ((float2*)dfd.p)[(size_t)lvl * fs.N + n] = make_float2(v0, v1);
-              ((float2*)dfd.p)[(size_t)(lvl + 1) * fs.N + n] = make_float2(v2, v3);
+          for (int g = 0; g < 4; ++g) {
+            // registers 4g..4g+3 <-> features 8g+4h .. 8g+4h+3 = levels 4g+2h, 4g+2h+1
+            const float v0 = a[0][4 * g], v1 = a[0][4 * g + 1], v2 = a[0][4 * g + 2], v3 = a[0][4 * g + 3];
+            const int lvl = 4 * g + 2 * h;
+            if (LAYOUT == HBR_LAYOUT_PLANAR) {
+              if (DT == HBR_F32) {
+                ((float2*)dfd.p)[(size_t)lvl * fs.N + n] = make_float2(v0, v1);
+                ((float2*)dfd.p)[(size_t)(lvl + 1) * fs.N + n] = make_float2(v2, v3);
+              } else {
+                ((uint32_t*)dfd.p)[(size_t)lvl * fs.N + n] = pack_bf16x2(v0, v1);
+                ((uint32_t*)dfd.p)[(size_t)(lvl + 1) * fs.N + n] = pack_bf16x2(v2, v3);
+              }
             } else {
-              ((uint32_t*)dfd.p)[(size_t)lvl * fs.N + n] = pack_bf16x2(v0, v1);
-              ((uint32_t*)dfd.p)[(size_t)(lvl + 1) * fs.N + n] = pack_bf16x2(v2, v3);
-            }
-          } else {
-            if (DT == HBR_F32) {
-              *(float4*)((float*)dfd.p + (size_t)n * dfd.stride + 2 * lvl) = make_float4(v0, v1, v2, v3);
-            } else {
-              uint2 u = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
-              *(uint2*)((uint16_t*)dfd.p + (size_t)n * dfd.stride + 2 * lvl) = u;
+              if (DT == HBR_F32) {
+                *(float4*)((float*)dfd.p + (size_t)n * dfd.stride + 2 * lvl) = make_float4(v0, v1, v2, v3);
+              } else {
+                uint2 u = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                *(uint2*)((uint16_t*)dfd.p + (size_t)n * dfd.stride + 2 * lvl) = u;
+              }
             }
           }
         }
       }
+    }
+  }
+
+  // ---- each wave adds its register accumulators to the workgroup image once (ds_add_f32, off the hot loop)
+#pragma unroll
+  for (int l = 0; l < NLAYER; ++l) {
+    const bool mine = (l <= L3) ? kSig : kCol;
+    if (!mine) continue;
+    const int nt = ((l == L3 || l == C3) ? 1 : 2) * ((l == L1) ? 1 : 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i >= nt) continue;
+      float* t = dw + ((dw_tile_base(l) + i) * 16) * 64 + lane;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) atomicAdd(t + q * 64, A.t[dw_tile_base(l) + i][q]);
+    }
+    const int nb = (l == L3 || l == C3) ? 1 : 2;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      if (m < nb) atomicAdd(db + l * 64 + 32 * m + (lane & 31), A.b[db_base(l) + m]);
     }
   }
 
@@ -675,14 +735,14 @@ static void launch_fwd(int dt, uint32_t blocks, hipStream_t st, const char* img,
   }
 }
 
-template <class P, int LAYOUT, int DT, int NWAVES, bool WLDS>
+template <class P, int LAYOUT, int DT, int NWAVES, bool WLDS, int PART>
 static void launch_bwd1(uint32_t ntiles, hipStream_t st, const char* img, FeatSrc fs, PeSrc ps, const float* dout, DFeatDst dfd,
                         float* dparams) {
   using T = Tab<P>;
   const int lds = kDwBytes + kDbBytes + (WLDS ? T::IMG_BYTES : 0);
   uint32_t blocks = (ntiles + NWAVES - 1) / NWAVES;
   if (blocks > 256) blocks = 256;  // one workgroup per CU (LDS-bound); each sweeps its share of the tiles
-  auto k = mlp_bwd_kernel<P, LAYOUT, DT, NWAVES, WLDS>;
+  auto k = mlp_bwd_kernel<P, LAYOUT, DT, NWAVES, WLDS, PART>;
   hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(k, dim3(blocks), dim3(NWAVES * 64), lds, st, img, fs, ps, dout, dfd, dparams);
 }
@@ -690,8 +750,14 @@ static void launch_bwd1(uint32_t ntiles, hipStream_t st, const char* img, FeatSr
 template <int LAYOUT, int DT>
 static void launch_bwd(int precision, uint32_t ntiles, hipStream_t st, const char* img, FeatSrc fs, PeSrc ps, const float* dout,
                        DFeatDst dfd, float* dparams) {
-  if (precision == HBR_BF16) launch_bwd1<PBf16, LAYOUT, DT, 8, true>(ntiles, st, img, fs, ps, dout, dfd, dparams);
-  else launch_bwd1<PF32, LAYOUT, DT, 4, false>(ntiles, st, img, fs, ps, dout, dfd, dparams);
+  // one wave per SIMD (4 waves per workgroup): the whole 512-register file per wave holds the dW accumulators
+  if (precision == HBR_BF16) {
+    launch_bwd1<PBf16, LAYOUT, DT, 4, true, HBR_BWD_PART_A>(ntiles, st, img, fs, ps, dout, dfd, dparams);
+    if (HBR_BWD_PART_A != 0) launch_bwd1<PBf16, LAYOUT, DT, 4, true, 2>(ntiles, st, img, fs, ps, dout, dfd, dparams);
+  } else {
+    launch_bwd1<PF32, LAYOUT, DT, 4, false, 1>(ntiles, st, img, fs, ps, dout, dfd, dparams);
+    launch_bwd1<PF32, LAYOUT, DT, 4, false, 2>(ntiles, st, img, fs, ps, dout, dfd, dparams);
+  }
 }
 
 static int check_common(const void* feat, int layout, int64_t stride, int dt, const float* pe, int64_t N, int64_t group,
