@@ -7,8 +7,8 @@
 // tables at L=16, T=2^16) instead of thrashing on all 8 MiB.  Placement is a speed assumption
 // only; results do not depend on it.
 //
-// Backward: (algo 1) one float atomic per corner-feature; (algo 2) a workgroup owns one
-// 8192-row slice of one level in LDS as fp64 accumulators (128 KiB), sweeps a chunk of the points,
+// Backward: (algo 1) one float atomic per corner-feature; (algo 2) a workgroup owns one feature of a
+// 16384-row slice of one level in LDS as fp64 accumulators (128 KiB), sweeps a chunk of the points,
 // accumulates the corners that fall into its slice with ds_add_f64 and flushes the slice once with
 // contiguous 256-B global float atomics (MI355X_MICROARCH "Global float atomics": contiguous atomics
 // run 17x the one-row-per-lane rate).  fp64 because on gfx950 ds_add_f32 costs ~190 cycles per
@@ -136,24 +136,28 @@ __global__ __launch_bounds__(kFwdThreads) void hash_bwd_atomic_kernel(PointSrc p
 // ------------------------------------------------------------------------------------------------
 // K2 backward, algo 2: LDS-resident table slice per workgroup
 // ------------------------------------------------------------------------------------------------
-constexpr int kSliceLog2 = 13;                 // 8192 rows * 2 doubles * 8 B = 128 KiB of the CU's 160 KiB LDS
+constexpr int kSliceLog2 = 14;                 // 16384 rows * 1 double * 8 B = 128 KiB of the CU's 160 KiB LDS
 constexpr int kSliceRows = 1 << kSliceLog2;
 constexpr int kLdsBwdThreads = 1024;
 
+// One workgroup = (level, 16384-row slice, feature f, chunk of points).  Splitting the two features of a row over
+// two workgroups keeps the slice at 16384 rows with fp64 accumulators, so a point is still visited 8 times per
+// level (4 slices x 2 features) but each visit issues 8 LDS atomics instead of 16.
 template <bool POW2, int LAYOUT, int DTYPE>
 __global__ __launch_bounds__(kLdsBwdThreads) void hash_bwd_lds_kernel(PointSrc ps, uint32_t N, const void* __restrict__ dy,
                                                                       int64_t dy_stride, HashGeom g,
                                                                       float* __restrict__ dtables, int slices_per_level,
                                                                       int chunks) {
-  extern __shared__ double acc[];  // [kSliceRows][2]
-  // block -> (level, slice, chunk); chunk varies fastest so the blocks of one (level, slice) start together
+  extern __shared__ double acc[];  // [kSliceRows]
+  // block -> (level, slice, feature, chunk); chunk varies fastest so the blocks of one slice start together
   const uint32_t b = blockIdx.x;
   const uint32_t chunk = b % chunks;
-  const uint32_t ls = b / chunks;
-  const uint32_t slice = ls % slices_per_level;
-  const int l = ls / slices_per_level;
+  const uint32_t lsf = b / chunks;
+  const int f = lsf & 1;
+  const uint32_t slice = (lsf >> 1) % slices_per_level;
+  const int l = (lsf >> 1) / slices_per_level;
 
-  for (int i = threadIdx.x; i < kSliceRows * 2; i += kLdsBwdThreads) acc[i] = 0.0;
+  for (int i = threadIdx.x; i < kSliceRows; i += kLdsBwdThreads) acc[i] = 0.0;
   __syncthreads();
 
   const uint32_t row_lo = slice << kSliceLog2;
@@ -166,6 +170,7 @@ __global__ __launch_bounds__(kLdsBwdThreads) void hash_bwd_lds_kernel(PointSrc p
     float px, py, pz, nx, ny, nz, d0, d1;
     load_point(ps, n, px, py, pz);
     load_feat<LAYOUT, DTYPE>(dy, n, l, N, dy_stride, d0, d1);
+    const float dv = f ? d1 : d0;
     normalise(g, px, py, pz, nx, ny, nz);
     Cell c = locate(nx, ny, nz, scale);
     uint32_t rows[8];
@@ -177,22 +182,21 @@ __global__ __launch_bounds__(kLdsBwdThreads) void hash_bwd_lds_kernel(PointSrc p
       uint32_t rel = rows[k] - row_lo;  // wraps to a huge value when the row is below the slice
       if (rel < (uint32_t)kSliceRows) {
 #ifdef HBR_ABL_NO_DSADD
-        asm volatile("" ::"v"(rel), "v"(__fmul_rn(w[k], d0)), "v"(__fmul_rn(w[k], d1)));
+        asm volatile("" ::"v"(rel), "v"(__fmul_rn(w[k], dv)));
 #else
-        atomicAdd(&acc[rel * 2 + 0], (double)__fmul_rn(w[k], d0));
-        atomicAdd(&acc[rel * 2 + 1], (double)__fmul_rn(w[k], d1));
+        atomicAdd(&acc[rel], (double)__fmul_rn(w[k], dv));
 #endif
       }
     }
   }
   __syncthreads();
 
-  // flush: contiguous 256-B wave-instructions of float atomics; skip exact zeros (untouched rows)
+  // flush: contiguous wave-instructions of float atomics (stride 2 floats); skip exact zeros (untouched rows)
   const int64_t rows_here = min((int64_t)kSliceRows, g.T - (int64_t)row_lo);
-  float* out = dtables + ((size_t)l * g.T + row_lo) * 2;
-  for (int64_t i = threadIdx.x; i < rows_here * 2; i += kLdsBwdThreads) {
+  float* out = dtables + ((size_t)l * g.T + row_lo) * 2 + f;
+  for (int64_t i = threadIdx.x; i < rows_here; i += kLdsBwdThreads) {
     const float v = (float)acc[i];
-    if (v != 0.f) unsafeAtomicAdd(out + i, v);
+    if (v != 0.f) unsafeAtomicAdd(out + 2 * i, v);
   }
 }
 
@@ -217,17 +221,17 @@ static void launch_bwd(int algo, hipStream_t st, PointSrc ps, uint32_t N, const 
   } else {
     const int spl = (int)((g.T + kSliceRows - 1) / kSliceRows);
     // enough chunks to give every CU a block (256 CUs), at most one chunk per 1024-point stripe
-    int chunks = (512 + g.L * spl - 1) / (g.L * spl);
+    int chunks = (512 + g.L * spl * 2 - 1) / (g.L * spl * 2);
     int max_chunks = (int)((N + kLdsBwdThreads - 1) / kLdsBwdThreads);
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1) chunks = 1;
     static bool attr_set[2][2][2] = {};
     auto kern = hash_bwd_lds_kernel<POW2, LAYOUT, DTYPE>;
     if (!attr_set[POW2][LAYOUT][DTYPE]) {
-      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kSliceRows * 2 * sizeof(double));
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kSliceRows * sizeof(double));
       attr_set[POW2][LAYOUT][DTYPE] = true;
     }
-    hipLaunchKernelGGL(kern, dim3((uint32_t)(g.L * spl * chunks)), dim3(kLdsBwdThreads), kSliceRows * 2 * sizeof(double), st, ps, N,
+    hipLaunchKernelGGL(kern, dim3((uint32_t)(g.L * spl * 2 * chunks)), dim3(kLdsBwdThreads), kSliceRows * sizeof(double), st, ps, N,
                        dy, stride, g, dtables, spl, chunks);
   }
 }
@@ -238,10 +242,10 @@ static int check_points(const float* x, const float* o, const float* d, const fl
   if (R * S > 0x7fffffffLL) return HBR_EUNSUPPORTED;
   N = (uint32_t)(R * S);
   if (x) {
-    ps = PointSrc{x, nullptr, nullptr, nullptr, (uint32_t)S};
+    ps = make_point_src(x, nullptr, nullptr, nullptr, (uint32_t)S);
   } else {
     if (!o || !d || !t) return HBR_EINVAL;
-    ps = PointSrc{nullptr, o, d, t, (uint32_t)S};
+    ps = make_point_src(nullptr, o, d, t, (uint32_t)S);
   }
   return HBR_OK;
 }

@@ -38,14 +38,25 @@ struct PointSrc {
   const float* d;
   const float* t;
   uint32_t S;
+  uint32_t magic, shift;  // n / S == (umulhi(n, magic) + n) >> shift for n < 2^31 (host: make_point_src)
 };
+
+// round-up magic number for dividing 31-bit n by S (Hacker's Delight 10-9, the "add" form): exact for n < 2^31
+inline PointSrc make_point_src(const float* x, const float* o, const float* d, const float* t, uint32_t S) {
+  PointSrc ps{x, o, d, t, S, 0u, 0u};
+  uint32_t sh = 0;
+  while ((1ull << sh) < S) ++sh;
+  ps.shift = sh;
+  ps.magic = (uint32_t)(((1ull << 32) * ((1ull << sh) - S)) / S + 1);
+  return ps;
+}
 
 __device__ __forceinline__ void load_point(const PointSrc& ps, uint32_t n, float& px, float& py, float& pz) {
   if (ps.x) {
     const float* p = ps.x + (size_t)n * 3;
     px = p[0]; py = p[1]; pz = p[2];
   } else {
-    uint32_t r = n / ps.S;
+    uint32_t r = (__umulhi(n, ps.magic) + n) >> ps.shift;
     uint32_t s = n - r * ps.S;
     float tt = ps.t[s];
     const float* o = ps.o + (size_t)r * 3;
