@@ -470,3 +470,95 @@ def test_training_converges_bf16_matches_fp32_psnr():
         res[prec] = (p0, p1)
     assert res[F32][1] > res[F32][0] + 3 and res[BF16][1] > res[BF16][0] + 3, res
     assert abs(res[F32][1] - res[BF16][1]) < 0.5, res
+
+
+# ------------------------------------------------------------------------------------------------ next rows (f2, f3)
+def test_checkpoint_roundtrip_reference_format(tmp_path):
+    """f3: files with the reference's names and keys (train_hash2.py:299-300) load into the drop-in modules and
+    render identically; bounds file as train_hash2.py:115 / nerf2mesh.py:28-29."""
+    from hbr_amd import checkpoint as ck
+    g = load_golden("g8_render_step.npz")
+    enc, mlp, vr = _build_modules(g)
+    # a "reference-written" checkpoint: plain dicts of tensors under the reference's key names
+    sd_n = {"module." + k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("a.")}
+    sd_e = {f"Embedding_list.{i}.weight": torch.from_numpy(g["tables_after"][i]) for i in range(int(g["L"]))}
+    assert list(sd_n.keys()) == list(g["state_keys_mlp"]) and list(sd_e.keys()) == list(g["state_keys_enc"])
+    torch.save(sd_n, tmp_path / "N_2048_T_16_Nerf_hash.pth")
+    torch.save(sd_e, tmp_path / "N_2048_T_16_encoder_hash.pth")
+    ck.load_checkpoint("N_2048_T_16", mlp, enc, directory=str(tmp_path))
+    o, d, dn, t = (T_(g[k]) for k in ("o", "d", "dir_norm", "t"))
+    with torch.no_grad():
+        _, C, _ = vr.vol_render(mlp, d, o, num_samples=t.shape[0], t=t, update_mask=True, dir_norm=dn, hierarchical=False)
+    assert np.allclose(C.cpu().numpy(), g["Cr_after_unmasked"], rtol=1e-4, atol=1e-5)  # the reference's own render of these weights
+    p1, p2 = ck.save_checkpoint("mine", mlp, enc, directory=str(tmp_path))
+    back = torch.load(p1, weights_only=True)
+    assert list(back.keys()) == list(g["state_keys_mlp"])
+    assert torch.equal(torch.load(p2, weights_only=True)["Embedding_list.3.weight"], sd_e["Embedding_list.3.weight"])
+    mn, mx = torch.tensor([-1.0, -2.0, -3.0]), torch.tensor([1.0, 2.0, 4.0])
+    ck.save_bounds(mn, mx, str(tmp_path / "bounds_model.npy"))
+    mn2, mx2, mu, sigma = ck.load_bounds(str(tmp_path / "bounds_model.npy"))
+    assert torch.equal(mn2, mn) and torch.equal(mx2, mx) and abs(float(sigma) - float(((mx - mn) ** 2).sum().sqrt())) < 1e-6
+
+
+def test_dense_grid_query_matches_oracle():
+    """f2: nerf2mesh.py:26-88's grid query (fp16-rounded lattice, fixed view dir (0,0,1), [res,res,res,4] output)
+    against the oracle's encoder+MLP on the same points."""
+    from hbr_amd.grid_query import grid_coordinates, query_density_grid
+    g = load_golden("g8_render_step.npz")
+    enc, mlp, vr = _build_modules(g)
+    mn = torch.from_numpy(g["mu"])
+    mx = mn + float(g["sigma"]) / np.sqrt(3.0)
+    res = 24
+    grid = query_density_grid(enc, mlp, mn, mx, res=res, batch=5000)
+    assert grid.shape == (res, res, res, 4)
+    pts = grid_coordinates(mn, mx, res, "cpu")
+    # the fp16 quirk: lattice points are fp16-representable
+    assert torch.equal(pts, pts.half().float())
+    tabs = [torch.from_numpy(g["tables"][l]) for l in range(int(g["L"]))]
+    prm = {k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("p.")}
+    sc = ref_cpu.level_scales(16, 2048.0, int(g["L"]))
+    feat = ref_cpu.hash_encode(pts, tabs, sc, mn, torch.tensor(float(g["sigma"])))
+    pe = ref_cpu.dir_encode(torch.tensor([[0.0, 0.0, 1.0]]), 4).expand(pts.shape[0], 24)
+    ref = ref_cpu.mlp_forward(feat, pe, prm).reshape(res, res, res, 4)
+    assert torch.allclose(grid.cpu(), ref, rtol=1e-4, atol=1e-5)
+
+
+def test_hip_training_tracks_cpu_oracle_psnr():
+    """PSNR vs reference (BASELINE metric, second half): 12 fp32 train steps of the HIP trainer against the CPU oracle's
+    train_step from identical initial parameters, rays and jitter: loss curves agree to 1e-3 relative and the final
+    PSNR on held-out rays within 0.1 dB."""
+    from hbr_amd._lib import F32
+    from hbr_amd.helper import calc_psnr
+    from hbr_amd.trainer import HashNeRFTrainer, build_default_model
+    R, S, L, T, steps = 192, 24, 16, 2 ** 10, 12
+    o0, d0, _, _ = ref_cpu.synthetic_rays(4096, seed=0)
+    mn, mx, sig = ref_cpu.bbox_mu_sigma(o0, d0)
+    rng = np.random.default_rng(7)
+    tables = torch.from_numpy(rng.uniform(-1e-2, 1e-2, (L, T, 2)).astype(np.float32))
+    params = ref_cpu.mlp_init(8)
+    tt = ref_cpu.strat_jitter_to_t(2.0, 6.0, S, torch.from_numpy(rng.uniform(0, 1, S).astype(np.float32)))
+    batches = [ref_cpu.synthetic_rays(R, seed=50 + i) for i in range(steps)]
+    test = ref_cpu.synthetic_rays(R, seed=999)
+    # CPU oracle
+    tabs = [tables[l].clone().requires_grad_(True) for l in range(L)]
+    prm = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    sc = ref_cpu.level_scales(16, 2048.0, L)
+    opts = ref_cpu.make_optimizers(tabs, prm.values(), steps)
+    ref_losses = [float(ref_cpu.train_step(b, tt, tabs, sc, mn, sig, prm, opts)) for b in batches]
+    with torch.no_grad():
+        C_ref, _, _ = ref_cpu.render(test[0], test[1], tt, test[2], tabs, sc, mn, sig, prm)
+    psnr_ref = float(ref_cpu.psnr(C_ref, test[3]))
+    # HIP
+    enc, denc, mlp = build_default_model(mn, sig, DEV, L=L, T=T, seed=0)
+    with torch.no_grad():
+        for l in range(L):
+            enc.Embedding_list[l].weight.copy_(tables[l])
+        for k, v in params.items():
+            seq, idx, kind = k.split(".")
+            getattr(getattr(mlp, seq)[int(idx)], kind).copy_(v)
+    tr = HashNeRFTrainer(enc, mlp, num_samples=S, total_steps=steps, precision=F32)
+    losses = [float(tr.step(*(a.to(DEV) for a in b), t=tt.to(DEV))) for b in batches]
+    assert np.allclose(losses, ref_losses, rtol=1e-3), (losses, ref_losses)
+    C = tr.render(test[0].to(DEV), test[1].to(DEV), test[2].to(DEV), t=tt.to(DEV))
+    psnr = float(calc_psnr(C.cpu(), test[3]))
+    assert abs(psnr - psnr_ref) < 0.1, (psnr, psnr_ref)
