@@ -21,6 +21,11 @@ namespace hbr {
 constexpr int kFwdThreads = 256;
 constexpr int kXcds = 8;
 
+// j-th level of XCD group `group`: groups pair a coarse level (cheap: the wave's gathers coalesce) with a fine one
+// (texture-rate bound) - {k, 15-k} for L = 16 - so that the 8 XCDs finish together; each XCD's L2 still only sees
+// L/8 levels.
+__device__ __forceinline__ int group_level(int group, int j) { return 8 * j + ((j & 1) ? 7 - group : group); }
+
 template <int LAYOUT, int DTYPE>
 __device__ __forceinline__ void store_feat(void* y, uint32_t n, int l, uint32_t N, int64_t stride, float f0, float f1) {
   size_t off = (LAYOUT == HBR_LAYOUT_PLANAR) ? ((size_t)l * N + n) * 2 : (size_t)n * stride + (size_t)l * 2;
@@ -69,15 +74,15 @@ __global__ __launch_bounds__(kFwdThreads) void hash_fwd_kernel(PointSrc ps, uint
   const int group = blockIdx.x % kXcds;
   const uint32_t tile = blockIdx.x / kXcds;
   const uint32_t n = tile * kFwdThreads + threadIdx.x;
-  const int l0 = group * levels_per_group;
-  if (l0 >= g.L || n >= N) return;
-  const int l1 = min(g.L, l0 + levels_per_group);
+  if (n >= N) return;
 
   float px, py, pz, nx, ny, nz;
   load_point(ps, n, px, py, pz);
   normalise(g, px, py, pz, nx, ny, nz);
 
-  for (int l = l0; l < l1; ++l) {
+  for (int j = 0; j < levels_per_group; ++j) {
+    const int l = group_level(group, j);
+    if (l >= g.L) continue;
     Cell c = locate(nx, ny, nz, g.scale[l]);
     uint32_t rows[8];
     float w[8];
@@ -108,15 +113,15 @@ __global__ __launch_bounds__(kFwdThreads) void hash_bwd_atomic_kernel(PointSrc p
   const int group = blockIdx.x % kXcds;
   const uint32_t tile = blockIdx.x / kXcds;
   const uint32_t n = tile * kFwdThreads + threadIdx.x;
-  const int l0 = group * levels_per_group;
-  if (l0 >= g.L || n >= N) return;
-  const int l1 = min(g.L, l0 + levels_per_group);
+  if (n >= N) return;
 
   float px, py, pz, nx, ny, nz;
   load_point(ps, n, px, py, pz);
   normalise(g, px, py, pz, nx, ny, nz);
 
-  for (int l = l0; l < l1; ++l) {
+  for (int j = 0; j < levels_per_group; ++j) {
+    const int l = group_level(group, j);
+    if (l >= g.L) continue;
     float d0, d1;
     load_feat<LAYOUT, DTYPE>(dy, n, l, N, dy_stride, d0, d1);
     Cell c = locate(nx, ny, nz, g.scale[l]);

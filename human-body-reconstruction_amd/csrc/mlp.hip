@@ -276,37 +276,62 @@ struct FeatSrc {
   uint32_t N;
 };
 
-// one point's 32 features -> the S32 fragments of the single input tile
-template <class P, int LAYOUT, int DT>
-__device__ __forceinline__ void load_feat_frags(const FeatSrc& fs, uint32_t n, bool valid, int h, typename P::frag (&x)[P::S32]) {
+struct PeSrc {
+  const float* pe;  // [G,24] encoded view directions
+  uint32_t group;   // points per row of pe (S for per-ray directions, 1 for per-point)
+};
+
+// raw per-lane inputs of one 32-point tile; loaded one tile ahead of use in the backward kernel (software prefetch:
+// with one or two waves per SIMD nothing else hides the HBM latency of these loads)
+struct TileIn {
+  float2 v[8];              // (f0,f1) of the lane's 8 levels
+  float4 peA, peB, peC;     // the lane's 12 direction-encoding values
+  float4 dO;                // d out (backward only)
+};
+
+template <int LAYOUT, int DT, bool WITH_DOUT>
+__device__ __forceinline__ void load_tile_in(const FeatSrc& fs, const PeSrc& ps, const float* dout, uint32_t n, bool valid, int h,
+                                             TileIn& ti) {
   // feature pair (2l, 2l+1) of level l; a lane in half h owns levels {2h,2h+1, 4+2h,4+2h+1, 8+.., 12+..}
-  float2 v[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int lvl = 4 * (k >> 1) + 2 * h + (k & 1);
-    v[k] = make_float2(0.f, 0.f);
+    ti.v[k] = make_float2(0.f, 0.f);
     if (valid) {
       if (LAYOUT == HBR_LAYOUT_PLANAR) {
-        if (DT == HBR_F32) v[k] = ((const float2*)fs.p)[(size_t)lvl * fs.N + n];
-        else { uint32_t u = ((const uint32_t*)fs.p)[(size_t)lvl * fs.N + n]; v[k] = make_float2(bf16_lo(u), bf16_hi(u)); }
+        if (DT == HBR_F32) ti.v[k] = ((const float2*)fs.p)[(size_t)lvl * fs.N + n];
+        else { uint32_t u = ((const uint32_t*)fs.p)[(size_t)lvl * fs.N + n]; ti.v[k] = make_float2(bf16_lo(u), bf16_hi(u)); }
       } else {
-        if (DT == HBR_F32) v[k] = *(const float2*)((const float*)fs.p + (size_t)n * fs.stride + 2 * lvl);
-        else { uint32_t u = *(const uint32_t*)((const uint16_t*)fs.p + (size_t)n * fs.stride + 2 * lvl); v[k] = make_float2(bf16_lo(u), bf16_hi(u)); }
+        if (DT == HBR_F32) ti.v[k] = *(const float2*)((const float*)fs.p + (size_t)n * fs.stride + 2 * lvl);
+        else { uint32_t u = *(const uint32_t*)((const uint16_t*)fs.p + (size_t)n * fs.stride + 2 * lvl); ti.v[k] = make_float2(bf16_lo(u), bf16_hi(u)); }
       }
     }
   }
+  ti.peA = make_float4(0, 0, 0, 0); ti.peB = ti.peA; ti.peC = ti.peA; ti.dO = ti.peA;
+  if (valid) {
+    const float* pr = ps.pe + (size_t)(n / ps.group) * 24;
+    ti.peA = *(const float4*)(pr + 4 * h);
+    ti.peB = *(const float4*)(pr + 8 + 4 * h);
+    ti.peC = *(const float4*)(pr + 16 + 4 * h);
+    if (WITH_DOUT && h == 0) ti.dO = ((const float4*)dout)[n];
+  }
+}
+
+// one point's 32 features -> the S32 fragments of the single input tile
+template <class P>
+__device__ __forceinline__ void feat_frags(const TileIn& ti, typename P::frag (&x)[P::S32]) {
   if constexpr (P::ELEMS == 8) {
     // step s, element j <-> feature 16s + 8(j>>2) + 4h + (j&3)  == levels 8s+2h, 8s+2h+1, 8s+4+2h, 8s+4+2h+1
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const float2 w[4] = {v[4 * s + 0], v[4 * s + 1], v[4 * s + 2], v[4 * s + 3]};
+      const float2 w[4] = {ti.v[4 * s + 0], ti.v[4 * s + 1], ti.v[4 * s + 2], ti.v[4 * s + 3]};
       x[s] = PBf16::feat_frag(w);
     }
   } else {
     // step q <-> feature (q&3) + 8(q>>2) + 4h : level 4(q>>2) + 2h + ((q&3)>>1), component q&1
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const float2 p = v[2 * (q >> 2) + ((q & 3) >> 1)];
+      const float2 p = ti.v[2 * (q >> 2) + ((q & 3) >> 1)];
       x[q] = (q & 1) ? p.y : p.x;
     }
   }
@@ -326,25 +351,14 @@ struct Saved {
   float raw[3];        // raw rgb (rows 0..2 of the C3 tile; h == 0 lanes)
 };
 
-struct PeSrc {
-  const float* pe;  // [G,24] encoded view directions
-  uint32_t group;   // points per row of pe (S for per-ray directions, 1 for per-point)
-};
 
-template <class P, int LAYOUT, int DT>
-__device__ __forceinline__ void forward_tile(const char* img, const float* bias, const FeatSrc& fs, const PeSrc& ps, uint32_t n,
-                                             bool valid, int lane, Saved<P>& sv) {
+template <class P>
+__device__ __forceinline__ void forward_tile(const char* img, const float* bias, const TileIn& ti, int lane, Saved<P>& sv) {
   using T = Tab<P>;
   const int h = lane >> 5;
   const int lofs = opaque_lane_offset<P>(lane);
-  load_feat_frags<P, LAYOUT, DT>(fs, n, valid, h, sv.x0);
-  float4 peA = make_float4(0, 0, 0, 0), peB = peA, peC = peA;
-  if (valid) {
-    const float* pr = ps.pe + (size_t)(n / ps.group) * 24;
-    peA = *(const float4*)(pr + 4 * h);
-    peB = *(const float4*)(pr + 8 + 4 * h);
-    peC = *(const float4*)(pr + 16 + 4 * h);
-  }
+  feat_frags<P>(ti, sv.x0);
+  const float4 peA = ti.peA, peB = ti.peB, peC = ti.peC;
   {
     f32x16 a[2];
     dense<P, 2, P::S32, true>(img, T::f_base(L1), bias + 64 * L1, lane, lofs, sv.x0, a);
@@ -407,7 +421,9 @@ __global__ __launch_bounds__(kFwdWaves * 64) void mlp_fwd_kernel(const char* __r
     const uint32_t n = tile * 32 + (lane & 31);
     const bool valid = n < fs.N;
     Saved<P> sv;
-    forward_tile<P, LAYOUT, DT>(smem, bias, fs, ps, n, valid, lane, sv);
+    TileIn ti;
+    load_tile_in<LAYOUT, DT, false>(fs, ps, nullptr, n, valid, lane >> 5, ti);
+    forward_tile<P>(smem, bias, ti, lane, sv);
     if (valid && lane < 32) {
       ((float4*)out)[n] = make_float4(elu1(sv.raw[0]), elu1(sv.raw[1]), elu1(sv.raw[2]), lrelu(sv.s0));
     }
@@ -418,9 +434,8 @@ __global__ __launch_bounds__(kFwdWaves * 64) void mlp_fwd_kernel(const char* __r
 // backward kernel
 // ------------------------------------------------------------------------------------------------
 constexpr int kDwTiles = 18;  // L1:2 L2:4 L3:2 C1:4 C2:4 C3:2
-#ifndef HBR_BWD_PART_A
-#define HBR_BWD_PART_A 1  // bf16: 1 = two launches (density net + d feat / colour net): 410 / 428 registers, no spills;
-                          //       0 = one launch with all 18 dW tiles resident (spills 532 B/lane with hipcc 7.2)
+#ifndef HBR_BWD_SPLIT
+#define HBR_BWD_SPLIT 2  // number of bf16 backward launches (2: one wave/SIMD; 3: two waves/SIMD)
 #endif
 __device__ __host__ constexpr int dw_tile_base(int l) {
   constexpr int b[NLAYER] = {0, 2, 6, 8, 12, 16};
@@ -501,9 +516,10 @@ struct DFeatDst {
   int64_t stride;
 };
 
-// PART selects which layers' weight gradients this launch produces (their accumulators live in registers):
-//   0 = all six layers, 1 = density net (L1..L3) + d feat, 2 = colour net (C1..C3) only (no L3..L1 back-propagation).
-template <class P, int LAYOUT, int DT, int NWAVES, bool WLDS, int PART>
+// WMASK (bit l = layer l) selects which layers' weight gradients this launch produces: their dW tiles live in
+// registers for the whole sweep.  Back-propagation stops below the shallowest selected layer; the launch that
+// selects L1 also writes d feat.
+template <class P, int LAYOUT, int DT, int NWAVES, bool WLDS, int WMASK>
 __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(const char* __restrict__ gimg, FeatSrc fs, PeSrc ps,
                                                               const float* __restrict__ dout, DFeatDst dfd,
                                                               float* __restrict__ dparams) {
@@ -519,7 +535,14 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(const char* __rest
   const float* bias = (const float*)(img + T::BIAS_OFF_ALL);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5;
   const uint32_t ntiles = (fs.N + 31) / 32;
-  constexpr bool kSig = PART != 2, kCol = PART != 1;
+  constexpr bool wC3 = (WMASK >> C3) & 1, wC2 = (WMASK >> C2) & 1, wC1 = (WMASK >> C1) & 1;
+  constexpr bool wL3 = (WMASK >> L3) & 1, wL2 = (WMASK >> L2) & 1, wL1 = (WMASK >> L1) & 1;
+  // how far back the data gradient has to travel for the selected layers
+  constexpr bool needC2 = WMASK & ((1 << C2) | (1 << C1) | (1 << L3) | (1 << L2) | (1 << L1));
+  constexpr bool needC1 = WMASK & ((1 << C1) | (1 << L3) | (1 << L2) | (1 << L1));
+  constexpr bool needL3 = WMASK & ((1 << L3) | (1 << L2) | (1 << L1));
+  constexpr bool needL2 = WMASK & ((1 << L2) | (1 << L1));
+  constexpr bool needL1 = WMASK & (1 << L1);
   DwAcc A;
 #pragma unroll
   for (int i = 0; i < kDwTiles; ++i)
@@ -528,14 +551,25 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(const char* __rest
 #pragma unroll
   for (int i = 0; i < 10; ++i) A.b[i] = 0.f;
 
+  TileIn nxt;
+  {
+    const uint32_t t0 = blockIdx.x * NWAVES + wv;
+    const uint32_t n0 = t0 * 32 + (lane & 31);
+    load_tile_in<LAYOUT, DT, true>(fs, ps, dout, n0, t0 < ntiles && n0 < fs.N, h, nxt);
+  }
   for (uint32_t tile = blockIdx.x * NWAVES + wv; tile < ntiles; tile += gridDim.x * NWAVES) {
     const uint32_t n = tile * 32 + (lane & 31);
     const bool valid = n < fs.N;
+    const TileIn cur = nxt;
+    {  // issue the next tile's loads now; they are consumed one iteration later
+      const uint32_t tn = tile + gridDim.x * NWAVES;
+      const uint32_t nn = tn * 32 + (lane & 31);
+      load_tile_in<LAYOUT, DT, true>(fs, ps, dout, nn, tn < ntiles && nn < fs.N, h, nxt);
+    }
     Saved<P> sv;
-    forward_tile<P, LAYOUT, DT>(img, bias, fs, ps, n, valid, lane, sv);
+    forward_tile<P>(img, bias, cur, lane, sv);
     const int lofs = opaque_lane_offset<P>(lane);
-    float4 dO = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid && h == 0) dO = ((const float4*)dout)[n];
+    const float4 dO = cur.dO;
 
     // ---- C3: dZc3 rows 0..2 = d rgb * elu'(raw)  (elu' = 1 for x>0 else exp(x))
     typename P::frag dz3[P::S8];
@@ -549,104 +583,116 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(const char* __rest
 #pragma unroll
       for (int s = 0; s < P::S8; ++s) dz3[s] = P::from_acc(a, s);
     }
-    if (kCol) {
+    if (wC3) {
       typename P::frag xt[2][P::S32], zt[1][P::S32];
       transpose_frags<P, 2, 2 * P::S32>(sv.c2, lane, xt);
       transpose_frags<P, 1, P::S8>(dz3, lane, zt);
       wgrad<P, C3, 2, 1>(A, xt, zt);
       bgrad<P, C3, 1>(A, zt);
     }
-    // ---- C2
-    typename P::frag dzc2[2 * P::S32];
-    {
-      f32x16 a[2];
-      dense<P, 2, P::S8, false>(img, T::b_base(C3), nullptr, lane, lofs, dz3, a);
-      mask_frags<P, 2>(a, sv.mc2, dzc2);
-      if (kCol) {
-        typename P::frag xt[2][P::S32], zt[2][P::S32];
-        transpose_frags<P, 2, 2 * P::S32>(sv.c1, lane, xt);
-        transpose_frags<P, 2, 2 * P::S32>(dzc2, lane, zt);
-        wgrad<P, C2, 2, 2>(A, xt, zt);
-        bgrad<P, C2, 2>(A, zt);
-      }
-    }
-    // ---- C1
-    typename P::frag dzc1[2 * P::S32];
-    {
-      f32x16 a[2];
-      dense<P, 2, 2 * P::S32, false>(img, T::b_base(C2), nullptr, lane, lofs, dzc2, a);
-      mask_frags<P, 2>(a, sv.mc1, dzc1);
-      if (kCol) {
-        typename P::frag xt[2][P::S32], zt[2][P::S32];
-        transpose_frags<P, 2, P::S32 + P::S8>(sv.cin, lane, xt);
-        transpose_frags<P, 2, 2 * P::S32>(dzc1, lane, zt);
-        wgrad<P, C1, 2, 2>(A, xt, zt);
-        bgrad<P, C1, 2>(A, zt);
-      }
-    }
-    if (kSig) {
-      // ---- L3: ds rows 1..15 = d cin slots 1..15 ; row 0 = d sigma * lrelu'(s0)
-      typename P::frag dz_s[P::S16];
-      {
-        f32x16 a[1];
-        dense<P, 1, 2 * P::S32, false>(img, T::b_base(C1), nullptr, lane, lofs, dzc1, a);
-        if (h == 0) a[0][0] = dO.w * (sv.s0 > 0.f ? 1.f : 0.01f);
-#pragma unroll
-        for (int s = 0; s < P::S16; ++s) dz_s[s] = P::from_acc(a[0], s);
-        typename P::frag xt[2][P::S32], zt[1][P::S32];
-        transpose_frags<P, 2, 2 * P::S32>(sv.h2, lane, xt);
-        transpose_frags<P, 1, P::S16>(dz_s, lane, zt);
-        wgrad<P, L3, 2, 1>(A, xt, zt);
-        bgrad<P, L3, 1>(A, zt);
-      }
-      // ---- L2
-      typename P::frag dz2[2 * P::S32];
+    if (needC2) {
+      // ---- C2
+      typename P::frag dzc2[2 * P::S32];
       {
         f32x16 a[2];
-        dense<P, 2, P::S16, false>(img, T::b_base(L3), nullptr, lane, lofs, dz_s, a);
-        mask_frags<P, 2>(a, sv.m2, dz2);
-        typename P::frag xt[2][P::S32], zt[2][P::S32];
-        transpose_frags<P, 2, 2 * P::S32>(sv.h1, lane, xt);
-        transpose_frags<P, 2, 2 * P::S32>(dz2, lane, zt);
-        wgrad<P, L2, 2, 2>(A, xt, zt);
-        bgrad<P, L2, 2>(A, zt);
+        dense<P, 2, P::S8, false>(img, T::b_base(C3), nullptr, lane, lofs, dz3, a);
+        mask_frags<P, 2>(a, sv.mc2, dzc2);
+        if (wC2) {
+          typename P::frag xt[2][P::S32], zt[2][P::S32];
+          transpose_frags<P, 2, 2 * P::S32>(sv.c1, lane, xt);
+          transpose_frags<P, 2, 2 * P::S32>(dzc2, lane, zt);
+          wgrad<P, C2, 2, 2>(A, xt, zt);
+          bgrad<P, C2, 2>(A, zt);
+        }
       }
-      // ---- L1
-      typename P::frag dz1[2 * P::S32];
-      {
-        f32x16 a[2];
-        dense<P, 2, 2 * P::S32, false>(img, T::b_base(L2), nullptr, lane, lofs, dz2, a);
-        mask_frags<P, 2>(a, sv.m1, dz1);
-        typename P::frag xt[1][P::S32], zt[2][P::S32];
-        transpose_frags<P, 1, P::S32>(sv.x0, lane, xt);
-        transpose_frags<P, 2, 2 * P::S32>(dz1, lane, zt);
-        wgrad<P, L1, 1, 2>(A, xt, zt);
-        bgrad<P, L1, 2>(A, zt);
-      }
-      // ---- d feat
-      if (dfd.p) {
-        f32x16 a[1];
-        dense<P, 1, 2 * P::S32, false>(img, T::b_base(L1), nullptr, lane, lofs, dz1, a);
-        if (valid) {
+      if (needC1) {
+        // ---- C1
+        typename P::frag dzc1[2 * P::S32];
+        {
+          f32x16 a[2];
+          dense<P, 2, 2 * P::S32, false>(img, T::b_base(C2), nullptr, lane, lofs, dzc2, a);
+          mask_frags<P, 2>(a, sv.mc1, dzc1);
+          if (wC1) {
+            typename P::frag xt[2][P::S32], zt[2][P::S32];
+            transpose_frags<P, 2, P::S32 + P::S8>(sv.cin, lane, xt);
+            transpose_frags<P, 2, 2 * P::S32>(dzc1, lane, zt);
+            wgrad<P, C1, 2, 2>(A, xt, zt);
+            bgrad<P, C1, 2>(A, zt);
+          }
+        }
+        if (needL3) {
+          // ---- L3: ds rows 1..15 = d cin slots 1..15 ; row 0 = d sigma * lrelu'(s0)
+          typename P::frag dz_s[P::S16];
+          {
+            f32x16 a[1];
+            dense<P, 1, 2 * P::S32, false>(img, T::b_base(C1), nullptr, lane, lofs, dzc1, a);
+            if (h == 0) a[0][0] = dO.w * (sv.s0 > 0.f ? 1.f : 0.01f);
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            // registers 4g..4g+3 <-> features 8g+4h .. 8g+4h+3 = levels 4g+2h, 4g+2h+1
-            const float v0 = a[0][4 * g], v1 = a[0][4 * g + 1], v2 = a[0][4 * g + 2], v3 = a[0][4 * g + 3];
-            const int lvl = 4 * g + 2 * h;
-            if (LAYOUT == HBR_LAYOUT_PLANAR) {
-              if (DT == HBR_F32) {
-                ((float2*)dfd.p)[(size_t)lvl * fs.N + n] = make_float2(v0, v1);
-                ((float2*)dfd.p)[(size_t)(lvl + 1) * fs.N + n] = make_float2(v2, v3);
-              } else {
-                ((uint32_t*)dfd.p)[(size_t)lvl * fs.N + n] = pack_bf16x2(v0, v1);
-                ((uint32_t*)dfd.p)[(size_t)(lvl + 1) * fs.N + n] = pack_bf16x2(v2, v3);
+            for (int s = 0; s < P::S16; ++s) dz_s[s] = P::from_acc(a[0], s);
+            if (wL3) {
+              typename P::frag xt[2][P::S32], zt[1][P::S32];
+              transpose_frags<P, 2, 2 * P::S32>(sv.h2, lane, xt);
+              transpose_frags<P, 1, P::S16>(dz_s, lane, zt);
+              wgrad<P, L3, 2, 1>(A, xt, zt);
+              bgrad<P, L3, 1>(A, zt);
+            }
+          }
+          if (needL2) {
+            // ---- L2
+            typename P::frag dz2[2 * P::S32];
+            {
+              f32x16 a[2];
+              dense<P, 2, P::S16, false>(img, T::b_base(L3), nullptr, lane, lofs, dz_s, a);
+              mask_frags<P, 2>(a, sv.m2, dz2);
+              if (wL2) {
+                typename P::frag xt[2][P::S32], zt[2][P::S32];
+                transpose_frags<P, 2, 2 * P::S32>(sv.h1, lane, xt);
+                transpose_frags<P, 2, 2 * P::S32>(dz2, lane, zt);
+                wgrad<P, L2, 2, 2>(A, xt, zt);
+                bgrad<P, L2, 2>(A, zt);
               }
-            } else {
-              if (DT == HBR_F32) {
-                *(float4*)((float*)dfd.p + (size_t)n * dfd.stride + 2 * lvl) = make_float4(v0, v1, v2, v3);
-              } else {
-                uint2 u = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
-                *(uint2*)((uint16_t*)dfd.p + (size_t)n * dfd.stride + 2 * lvl) = u;
+            }
+            if (needL1) {
+              // ---- L1
+              typename P::frag dz1[2 * P::S32];
+              {
+                f32x16 a[2];
+                dense<P, 2, 2 * P::S32, false>(img, T::b_base(L2), nullptr, lane, lofs, dz2, a);
+                mask_frags<P, 2>(a, sv.m1, dz1);
+                typename P::frag xt[1][P::S32], zt[2][P::S32];
+                transpose_frags<P, 1, P::S32>(sv.x0, lane, xt);
+                transpose_frags<P, 2, 2 * P::S32>(dz1, lane, zt);
+                wgrad<P, L1, 1, 2>(A, xt, zt);
+                bgrad<P, L1, 2>(A, zt);
+              }
+              // ---- d feat
+              if (dfd.p) {
+                f32x16 a[1];
+                dense<P, 1, 2 * P::S32, false>(img, T::b_base(L1), nullptr, lane, lofs, dz1, a);
+                if (valid) {
+#pragma unroll
+                  for (int g = 0; g < 4; ++g) {
+                    // registers 4g..4g+3 <-> features 8g+4h .. 8g+4h+3 = levels 4g+2h, 4g+2h+1
+                    const float v0 = a[0][4 * g], v1 = a[0][4 * g + 1], v2 = a[0][4 * g + 2], v3 = a[0][4 * g + 3];
+                    const int lvl = 4 * g + 2 * h;
+                    if (LAYOUT == HBR_LAYOUT_PLANAR) {
+                      if (DT == HBR_F32) {
+                        ((float2*)dfd.p)[(size_t)lvl * fs.N + n] = make_float2(v0, v1);
+                        ((float2*)dfd.p)[(size_t)(lvl + 1) * fs.N + n] = make_float2(v2, v3);
+                      } else {
+                        ((uint32_t*)dfd.p)[(size_t)lvl * fs.N + n] = pack_bf16x2(v0, v1);
+                        ((uint32_t*)dfd.p)[(size_t)(lvl + 1) * fs.N + n] = pack_bf16x2(v2, v3);
+                      }
+                    } else {
+                      if (DT == HBR_F32) {
+                        *(float4*)((float*)dfd.p + (size_t)n * dfd.stride + 2 * lvl) = make_float4(v0, v1, v2, v3);
+                      } else {
+                        uint2 u = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                        *(uint2*)((uint16_t*)dfd.p + (size_t)n * dfd.stride + 2 * lvl) = u;
+                      }
+                    }
+                  }
+                }
               }
             }
           }
@@ -658,8 +704,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(const char* __rest
   // ---- each wave adds its register accumulators to the workgroup image once (ds_add_f32, off the hot loop)
 #pragma unroll
   for (int l = 0; l < NLAYER; ++l) {
-    const bool mine = (l <= L3) ? kSig : kCol;
-    if (!mine) continue;
+    if (!((WMASK >> l) & 1)) continue;
     const int nt = ((l == L3 || l == C3) ? 1 : 2) * ((l == L1) ? 1 : 2);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -735,14 +780,14 @@ static void launch_fwd(int dt, uint32_t blocks, hipStream_t st, const char* img,
   }
 }
 
-template <class P, int LAYOUT, int DT, int NWAVES, bool WLDS, int PART>
+template <class P, int LAYOUT, int DT, int NWAVES, bool WLDS, int WMASK>
 static void launch_bwd1(uint32_t ntiles, hipStream_t st, const char* img, FeatSrc fs, PeSrc ps, const float* dout, DFeatDst dfd,
                         float* dparams) {
   using T = Tab<P>;
   const int lds = kDwBytes + kDbBytes + (WLDS ? T::IMG_BYTES : 0);
   uint32_t blocks = (ntiles + NWAVES - 1) / NWAVES;
   if (blocks > 256) blocks = 256;  // one workgroup per CU (LDS-bound); each sweeps its share of the tiles
-  auto k = mlp_bwd_kernel<P, LAYOUT, DT, NWAVES, WLDS, PART>;
+  auto k = mlp_bwd_kernel<P, LAYOUT, DT, NWAVES, WLDS, WMASK>;
   hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(k, dim3(blocks), dim3(NWAVES * 64), lds, st, img, fs, ps, dout, dfd, dparams);
 }
@@ -750,13 +795,28 @@ static void launch_bwd1(uint32_t ntiles, hipStream_t st, const char* img, FeatSr
 template <int LAYOUT, int DT>
 static void launch_bwd(int precision, uint32_t ntiles, hipStream_t st, const char* img, FeatSrc fs, PeSrc ps, const float* dout,
                        DFeatDst dfd, float* dparams) {
-  // one wave per SIMD (4 waves per workgroup): the whole 512-register file per wave holds the dW accumulators
+  constexpr int mSig = (1 << L1) | (1 << L2) | (1 << L3), mCol = (1 << C1) | (1 << C2) | (1 << C3);
+#if HBR_BWD_SPLIT == 1
   if (precision == HBR_BF16) {
-    launch_bwd1<PBf16, LAYOUT, DT, 4, true, HBR_BWD_PART_A>(ntiles, st, img, fs, ps, dout, dfd, dparams);
-    if (HBR_BWD_PART_A != 0) launch_bwd1<PBf16, LAYOUT, DT, 4, true, 2>(ntiles, st, img, fs, ps, dout, dfd, dparams);
-  } else {
-    launch_bwd1<PF32, LAYOUT, DT, 4, false, 1>(ntiles, st, img, fs, ps, dout, dfd, dparams);
-    launch_bwd1<PF32, LAYOUT, DT, 4, false, 2>(ntiles, st, img, fs, ps, dout, dfd, dparams);
+    launch_bwd1<PBf16, LAYOUT, DT, 4, true, mSig | mCol>(ntiles, st, img, fs, ps, dout, dfd, dparams);
+  } else
+#elif HBR_BWD_SPLIT == 3
+  // three launches, two waves per SIMD (<= 256 registers): {C3,C2}, {C1,L3}, {L2,L1 + d feat}
+  if (precision == HBR_BF16) {
+    launch_bwd1<PBf16, LAYOUT, DT, 8, true, (1 << C3) | (1 << C2)>(ntiles, st, img, fs, ps, dout, dfd, dparams);
+    launch_bwd1<PBf16, LAYOUT, DT, 8, true, (1 << C1) | (1 << L3)>(ntiles, st, img, fs, ps, dout, dfd, dparams);
+    launch_bwd1<PBf16, LAYOUT, DT, 8, true, (1 << L2) | (1 << L1)>(ntiles, st, img, fs, ps, dout, dfd, dparams);
+  } else
+#else
+  // two launches, one wave per SIMD (4 waves per workgroup, up to 512 registers): density net + d feat, colour net
+  if (precision == HBR_BF16) {
+    launch_bwd1<PBf16, LAYOUT, DT, 4, true, mSig>(ntiles, st, img, fs, ps, dout, dfd, dparams);
+    launch_bwd1<PBf16, LAYOUT, DT, 4, true, mCol>(ntiles, st, img, fs, ps, dout, dfd, dparams);
+  } else
+#endif
+  {
+    launch_bwd1<PF32, LAYOUT, DT, 4, false, mSig>(ntiles, st, img, fs, ps, dout, dfd, dparams);
+    launch_bwd1<PF32, LAYOUT, DT, 4, false, mCol>(ntiles, st, img, fs, ps, dout, dfd, dparams);
   }
 }
 
