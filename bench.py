@@ -57,11 +57,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev  # (rehearsals with more ranks than GPUs share a device; the real run has one GPU per rank)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        backend = os.environ.get("HBR_DIST_BACKEND", "nccl")  # nccl == RCCL on ROCm; gloo only for 1-GPU rehearsals
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
     assert _lib.lib().hbr_device_ok() == 1, "not a gfx950 device"
 
     R, S = args.rays, args.samples

@@ -171,7 +171,14 @@ __global__ __launch_bounds__(kLdsBwdThreads) void hash_bwd_lds_kernel(PointSrc p
   const uint32_t n_end = min(N, n_begin + per);
   const float scale = g.scale[l];
 
-  for (uint32_t n = n_begin + threadIdx.x; n < n_end; n += kLdsBwdThreads) {
+  // Within each 1024-point stripe the 64 lanes of a wave take points 16 apart (lane i of wave w -> offset 16 i + w):
+  // consecutive samples of a ray share their cell at the coarse levels, and 64 lanes adding to the same LDS address
+  // serialise (level 0 cost 3.2x a fine level with the natural mapping).  The stripe's 16 waves together still read
+  // every dy cache line completely, so the reads stay L1-friendly.
+  const uint32_t perm = (threadIdx.x & 63u) * (kLdsBwdThreads / 64) + (threadIdx.x >> 6);
+  for (uint32_t base = n_begin; base < n_end; base += kLdsBwdThreads) {
+    const uint32_t n = base + perm;
+    if (n >= n_end) continue;
     float px, py, pz, nx, ny, nz, d0, d1;
     load_point(ps, n, px, py, pz);
     load_feat<LAYOUT, DTYPE>(dy, n, l, N, dy_stride, d0, d1);
