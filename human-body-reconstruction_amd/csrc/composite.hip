@@ -32,6 +32,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 struct RayIn {
   const float* t;
+  int64_t t_stride;  // 0: one t[S] shared by all rays (vol_render's first pass); S: per-ray t[R,S] (hierarchical pass)
   const float* rgb;
   int64_t rgb_stride;
   const float* sigma;
@@ -45,7 +46,8 @@ __device__ __forceinline__ float sample_p(const RayIn& in, int64_t r, int64_t s,
   delta = 0.f;
   live = false;
   if (s >= in.S) return 0.f;
-  if (s < in.S - 1) delta = __fmul_rn(__fsub_rn(in.t[s + 1], in.t[s]), dn);  // helper.py:67,71; last delta stays 0
+  const float* tr = in.t + r * in.t_stride;
+  if (s < in.S - 1) delta = __fmul_rn(__fsub_rn(tr[s + 1], tr[s]), dn);  // helper.py:67,71; last delta stays 0
   float sg = in.sigma[(r * in.S + s) * in.sigma_stride];
   live = !(sg < -10.f);
   if (!live) sg = -10.f;
@@ -158,6 +160,7 @@ __global__ __launch_bounds__(256) void mse2_kernel(const float* __restrict__ Cr,
 
 static int check_ray_in(const RayIn& in) {
   if (!in.t || !in.rgb || !in.sigma || in.R < 0 || in.S < 1 || in.rgb_stride < 3 || in.sigma_stride < 1) return HBR_EINVAL;
+  if (in.t_stride != 0 && in.t_stride < in.S) return HBR_EINVAL;
   if (in.S > (int64_t)kMaxChunks * 64) return HBR_EUNSUPPORTED;
   return HBR_OK;
 }
@@ -166,10 +169,10 @@ static int check_ray_in(const RayIn& in) {
 
 using namespace hbr;
 
-extern "C" int hbr_composite_fwd(const float* t, const float* rgb, int64_t rgb_stride, const float* sigma,
+extern "C" int hbr_composite_fwd(const float* t, int64_t t_stride, const float* rgb, int64_t rgb_stride, const float* sigma,
                                  int64_t sigma_stride, const float* dir_norm, int64_t R, int64_t S, float* Cr, float* wts,
                                  void* stream) {
-  RayIn in{t, rgb, rgb_stride, sigma, sigma_stride, dir_norm, R, S};
+  RayIn in{t, t_stride, rgb, rgb_stride, sigma, sigma_stride, dir_norm, R, S};
   int rc = check_ray_in(in);
   if (rc) return rc;
   if (!Cr) return HBR_EINVAL;
@@ -181,10 +184,10 @@ extern "C" int hbr_composite_fwd(const float* t, const float* rgb, int64_t rgb_s
   return HBR_OK;
 }
 
-extern "C" int hbr_composite_bwd(const float* t, const float* rgb, int64_t rgb_stride, const float* sigma,
+extern "C" int hbr_composite_bwd(const float* t, int64_t t_stride, const float* rgb, int64_t rgb_stride, const float* sigma,
                                  int64_t sigma_stride, const float* dir_norm, int64_t R, int64_t S, const float* dCr,
                                  float* d_rgb, float* d_sigma, void* stream) {
-  RayIn in{t, rgb, rgb_stride, sigma, sigma_stride, dir_norm, R, S};
+  RayIn in{t, t_stride, rgb, rgb_stride, sigma, sigma_stride, dir_norm, R, S};
   int rc = check_ray_in(in);
   if (rc) return rc;
   if (!dCr || !d_rgb || !d_sigma) return HBR_EINVAL;

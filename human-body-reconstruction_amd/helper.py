@@ -45,15 +45,40 @@ def strat_sampler(tn, tf, num_samples: int, exp: Optional[bool] = False, device=
     return t + torch.rand_like(t) * float(tf - tn) / num_samples
 
 
+def hierarchical_sampling(rays_o: torch.Tensor, rays_d: torch.Tensor, z_vals: torch.Tensor, weights: torch.Tensor,
+                          n_samples: int, tn: float, tf: float, perturb: bool = False, device: str = "cuda",
+                          u: Optional[torch.Tensor] = None, samples01: Optional[torch.Tensor] = None):
+    """Inverse-CDF resampling of the reference's second pass (helper.py:23-51).  Returns (points [R, S+n, 3],
+    combined depths [R, S+n]).  Negative weights count as 0; the new depths index ONE shared random vector
+    `samples` of length n_samples (the reference's behaviour, helper.py:43-45), then merge-sort with z_vals.
+    `u` [R,S] / `samples01` [n] optionally supply the two uniform draws (parity tests); default: torch.rand."""
+    dev = weights.device
+    w = weights.detach().reshape(weights.shape[0], -1)
+    w = torch.where(w < 0, torch.zeros_like(w), w)
+    pdf = (w + 1e-5) / torch.sum(w + 1e-5, dim=-1, keepdim=True)
+    cdf = torch.cumsum(pdf, dim=-1)
+    if u is None:
+        u = torch.rand(cdf.shape, device=dev)
+    inds = torch.searchsorted(cdf, u.contiguous(), right=True)
+    if samples01 is None:
+        samples01 = torch.rand(n_samples, device=dev)
+    samples = samples01 * (float(tf) - float(tn)) + float(tn)
+    inds = torch.clamp(inds, min=0, max=samples.shape[-1] - 1)
+    samples = samples[inds]
+    z = z_vals.expand(list(inds.shape[:-1]) + [z_vals.shape[-1]])
+    combined, _ = torch.sort(torch.cat([z, samples], dim=-1), dim=-1)
+    rays = rays_o[..., None, :] + rays_d[..., None, :] * combined[..., :, None]
+    return rays, combined
+
+
 def calc_color(t, rgb, sigma, dir_norm, use_sdf: bool = False, var_model=None, rays=None, model=None, encoder=None,
                device: str = "cuda"):
     """Alpha compositing (helper.py:53-107, non-SDF branch): returns (Cr [R,3], wts [R,S,1], None).
     delta_last = 0, sigma clamped at -10 (zero gradient where clamped), negative sigma allowed."""
     if use_sdf:
         raise NotImplementedError("the SDF branch (helper.py:80-89) is out of scope (flag default off, train_hash2.py:33)")
-    if t.dim() != 1:
-        raise NotImplementedError("calc_color kernel takes the shared t[S] of vol_render; per-ray t is handled by "
-                                  "vol_renderer's hierarchical pass")
+    if t.dim() not in (1, 2):
+        raise ValueError("t must be [S] (shared) or [R,S] (per ray)")
     Cr, wts = ops.CompositeFn.apply(t, rgb, sigma, dir_norm)
     return Cr, wts[:, :, None], None
 

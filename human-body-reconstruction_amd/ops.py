@@ -170,16 +170,25 @@ def mlp_bwd(feat: torch.Tensor, layout: int, viewdirs_enc: torch.Tensor, group: 
     return dfeat
 
 
+def _t_stride(t, S):
+    """0 for the shared t[S]; S for a contiguous per-ray t[R,S]."""
+    return 0 if t.dim() == 1 else S
+
+
 def composite_fwd(t, rgb, rgb_stride, sigma, sigma_stride, dir_norm, R, S, want_wts=True):
     Cr = torch.empty((R, 3), dtype=torch.float32, device=t.device)
     wts = torch.empty((R, S), dtype=torch.float32, device=t.device) if want_wts else None
-    check(lib().hbr_composite_fwd(t.data_ptr(), rgb, rgb_stride, sigma, sigma_stride, _ptr(dir_norm), R, S, Cr.data_ptr(),
+    if R == 0:
+        return Cr, wts
+    check(lib().hbr_composite_fwd(t.data_ptr(), _t_stride(t, S), rgb, rgb_stride, sigma, sigma_stride, _ptr(dir_norm), R, S, Cr.data_ptr(),
                                   _ptr(wts), _stream()), "hbr_composite_fwd")
     return Cr, wts
 
 
 def composite_bwd(t, rgb, rgb_stride, sigma, sigma_stride, dir_norm, R, S, dCr, d_rgb, d_sigma):
-    check(lib().hbr_composite_bwd(t.data_ptr(), rgb, rgb_stride, sigma, sigma_stride, _ptr(dir_norm), R, S, dCr.data_ptr(),
+    if R == 0:
+        return
+    check(lib().hbr_composite_bwd(t.data_ptr(), _t_stride(t, S), rgb, rgb_stride, sigma, sigma_stride, _ptr(dir_norm), R, S, dCr.data_ptr(),
                                   d_rgb, d_sigma, _stream()), "hbr_composite_bwd")
 
 
@@ -267,6 +276,8 @@ class CompositeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t, rgb, sigma, dir_norm):
         R, S = sigma.shape
+        if t.dim() == 2 and tuple(t.shape) != (R, S):
+            raise ValueError("per-ray t must have sigma's shape [R,S]")
         t, rgb, sigma = _f32c(t.detach()), _f32c(rgb.detach()), _f32c(sigma.detach())
         dn = _dir_norm_arg(dir_norm, R, sigma.device)
         Cr, wts = composite_fwd(t, rgb.data_ptr(), 3, sigma.data_ptr(), 1, dn, R, S)
@@ -285,21 +296,28 @@ class CompositeFn(torch.autograd.Function):
 
 
 class RenderFn(torch.autograd.Function):
-    """The whole of vol_render (vol_renderer.py:141-245, hierarchical off, all-true occupancy mask):
+    """The whole of vol_render's field evaluation + compositing (vol_renderer.py:141-245, all-true occupancy mask):
     rays -> points -> hash features (planar) -> MLP -> composite, with one hand-written backward:
-    composite_bwd -> mlp_bwd (recomputes activations) -> hash scatter-add.  Nothing but the planar
-    feature buffer and the [N,4] MLP output is kept between forward and backward."""
+    composite_bwd -> mlp_bwd (recomputes activations) -> hash scatter-add.  Nothing but the planar feature buffer
+    and the [N,4] MLP output is kept between forward and backward.
+    t [S]: depths shared by all rays, points generated on chip (first pass).  t [R,S2]: per-ray depths of the
+    hierarchical pass (vol_renderer.py:226-242); points o + d*t are then materialised once."""
 
     @staticmethod
     def forward(ctx, rays_o, rays_d, t, dir_norm, geom, stacked, flat, precision, num_freq, splits, feat_dtype, n_tab, *params):
         o, d, t = _f32c(rays_o.detach()), _f32c(rays_d.detach()), _f32c(t.detach())
-        R, S = o.shape[0], t.shape[0]
+        R, S = o.shape[0], t.shape[-1]
         dn = _dir_norm_arg(dir_norm, R, o.device)
         pe = dir_encode(d, num_freq)
-        feat = hash_encode_fwd(geom, stacked, rays=(o, d, t), layout=PLANAR, dtype=feat_dtype)
+        if t.dim() == 1:
+            x, rays = None, (o, d, t)
+        else:
+            x, rays = (o[:, None, :] + d[:, None, :] * t[:, :, None]).reshape(-1, 3).contiguous(), None
+        feat = hash_encode_fwd(geom, stacked, x=x, rays=rays, layout=PLANAR, dtype=feat_dtype)
         out = mlp_fwd(feat, PLANAR, pe, S, flat, precision)
         Cr, wts = composite_fwd(t, out.data_ptr(), 4, out.data_ptr() + 12, 4, dn, R, S)
         ctx.save_for_backward(o, d, t, pe, feat, out)
+        ctx.x = x
         ctx.dn, ctx.geom, ctx.flat, ctx.precision, ctx.splits, ctx.n_tab = dn, geom, flat, precision, splits, n_tab
         ctx.mark_non_differentiable(wts, out)
         return Cr, wts, out
@@ -308,12 +326,13 @@ class RenderFn(torch.autograd.Function):
     def backward(ctx, dCr, _dw, _dout):
         o, d, t, pe, feat, out = ctx.saved_tensors
         g = ctx.geom
-        R, S = o.shape[0], t.shape[0]
+        R, S = o.shape[0], t.shape[-1]
         d_out = torch.empty_like(out)
         composite_bwd(t, out.data_ptr(), 4, out.data_ptr() + 12, 4, ctx.dn, R, S, _f32c(dCr), d_out.data_ptr(), d_out.data_ptr() + 12)
         dflat = torch.zeros_like(ctx.flat)
         dfeat = mlp_bwd(feat, PLANAR, pe, S, ctx.flat, ctx.precision, d_out, dflat)
         dtab = torch.zeros((g.L, g.T, g.F), dtype=torch.float32, device=o.device)
-        hash_encode_bwd(g, dfeat, dtab, rays=(o, d, t), layout=PLANAR)
+        rays = None if ctx.x is not None else (o, d, t)
+        hash_encode_bwd(g, dfeat, dtab, x=ctx.x, rays=rays, layout=PLANAR)
         grads = tuple(dtab[i] for i in range(ctx.n_tab)) + tuple(dflat[a:b].view(shape) for (a, b, shape) in ctx.splits)
         return (None,) * 12 + grads

@@ -46,6 +46,8 @@ class Volume_Renderer():
         self.feat_dtype = F32       # dtype of the planar feature buffer between K1 and K3 (F32 | BF16)
         self._grid_version = self.bool_grid._version
         self._grid_all_true = True
+        self.fine_rng = None        # optional callable -> (u [R,S], samples01 [S]) replacing torch.rand in the hierarchical pass
+        self.last_t_fine = None
         self.last_sigma = None      # [R,S] / [R,S,3] views of the last MLP output, for inspection and parity tests
         self.last_rgb = None
 

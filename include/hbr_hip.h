@@ -83,16 +83,17 @@ int64_t hbr_hash_bwd_workspace_bytes(int64_t N, int L, int64_t T, int F, int alg
 
 /* ---- K5: alpha compositing along rays ---------------------------------------------------------
  * Replaces calc_color, helper.py:53-107 (non-SDF branch).
- *   t [S] shared sample depths; rgb [R,S,3]; sigma [R,S]; dir_norm [R] (NULL => 1)
+ *   t [S] sample depths shared by all rays (t_stride = 0), or per-ray t [R, t_stride >= S] (the hierarchical
+ *   pass, vol_renderer.py:242); rgb [R,S,3]; sigma [R,S]; dir_norm [R] (NULL => 1)
  *   rgbs: alternatively rgb and sigma interleaved as the MLP's [R*S,4] (r,g,b,sigma) output:
  *         pass rgb = out, sigma = out+3 and elem strides rgb_stride = sigma_stride = 4
  *   Cr [R,3]; wts [R,S] (may be NULL)
  */
-int hbr_composite_fwd(const float* t, const float* rgb, int64_t rgb_stride, const float* sigma,
+int hbr_composite_fwd(const float* t, int64_t t_stride, const float* rgb, int64_t rgb_stride, const float* sigma,
                       int64_t sigma_stride, const float* dir_norm, int64_t R, int64_t S, float* Cr,
                       float* wts, void* stream);
 /* d_rgb / d_sigma use the same strides as their forward counterparts */
-int hbr_composite_bwd(const float* t, const float* rgb, int64_t rgb_stride, const float* sigma,
+int hbr_composite_bwd(const float* t, int64_t t_stride, const float* rgb, int64_t rgb_stride, const float* sigma,
                       int64_t sigma_stride, const float* dir_norm, int64_t R, int64_t S,
                       const float* dCr, float* d_rgb, float* d_sigma, void* stream);
 

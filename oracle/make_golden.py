@@ -302,6 +302,37 @@ def main():
     g8["state_keys_enc"] = np.array(list(enc.state_dict().keys()))
     np.savez_compressed(os.path.join(OUT, "g8_render_step.npz"), **g8)
 
+    # ---------------- G11/G12: hierarchical second pass (helper.py:23-51, vol_renderer.py:225-242) ----------
+    # The reference draws u = rand(R,S) then samples = rand(S) from torch's global CPU generator; seeding it and
+    # replaying the two draws gives the explicit random inputs the build's implementation takes as arguments.
+    enc = build_encoder(ref, tables, 2048.0, 16, mu, sigma)          # original (pre-step) weights
+    mlp = torch.nn.DataParallel(build_mlp(ref, params))
+    vr = ref.vol_renderer.Volume_Renderer(H=8, W=8, K=Kd, near=2.0, far=6.0, device="cpu", Pos_encode=enc,
+                                          Dir_encode=pe, max_dim=2 ** 10, sigma_val=torch.tensor(float(sigma)),
+                                          mu=torch.from_numpy(mu))
+    torch.manual_seed(1212)
+    u_draw = torch.rand(R, S)
+    smp_draw = torch.rand(S)
+    torch.manual_seed(1212)
+    Cr_h, Cf_h, _ = quiet(vr.vol_render, mlp, dvec, o, num_samples=S, t=torch.from_numpy(t), update_mask=False,
+                          dir_norm=dn, hierarchical=True)
+    loss_h = crit(Cr_h, gt) + crit(Cf_h, gt)
+    loss_h.backward()
+    g12 = dict(u=u_draw.numpy(), samples01=smp_draw.numpy(), Cr=Cr_h.detach().numpy(), Cf=Cf_h.detach().numpy(),
+               loss=loss_h.item(), dtables=np.stack([enc.Embedding_list[l].weight.grad.numpy() for l in range(L)]))
+    for name, p in mlp.module.named_parameters():
+        g12["g." + name] = p.grad.numpy()
+    # the sampler on its own, with weights that include negatives (clamped to 0 in place, helper.py:36)
+    wts_in = torch.from_numpy(f32(rng.standard_normal((R, S, 1)) * 0.3 + 0.2))
+    torch.manual_seed(1111)
+    u11 = torch.rand(R, S)
+    s11 = torch.rand(S)
+    torch.manual_seed(1111)
+    rays_f, t_f = quiet(ref.helper.hierarchical_sampling, o, dvec, z_vals=torch.from_numpy(t), weights=wts_in.clone(),
+                        n_samples=S, tn=2.0, tf=6.0, device="cpu")
+    g12.update(hs_weights=wts_in.numpy(), hs_u=u11.numpy(), hs_samples01=s11.numpy(), hs_rays=rays_f.numpy(), hs_t=t_f.numpy())
+    np.savez_compressed(os.path.join(OUT, "g12_hierarchical.npz"), **g12)
+
     # ---------------- G10: PSNR + bounding box -----------------------------------------
     a = torch.from_numpy(f32(rng.uniform(0, 1, (50, 3))))
     b = torch.from_numpy(f32(rng.uniform(0, 1, (50, 3))))

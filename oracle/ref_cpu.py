@@ -327,3 +327,53 @@ def bbox_mu_sigma(o: torch.Tensor, d: torch.Tensor, near: float = 2.0, far: floa
     mn = pts.min(dim=0).values
     mx = pts.max(dim=0).values
     return mn, mx, ((mx - mn) ** 2).sum().sqrt()
+
+
+# --------------------------------------------------------------------------------------
+# hierarchical second pass                        helper.py:23-51, vol_renderer.py:225-242
+# --------------------------------------------------------------------------------------
+def hierarchical_sample(o, d, t, weights, n_samples: int, tn: float, tf: float, u01: torch.Tensor, samples01: torch.Tensor):
+    """The reference's resampling with its two uniform draws made explicit (u01 [R,S], samples01 [n_samples]):
+    negative weights -> 0 (helper.py:36); pdf = (w+1e-5)/sum (:38); cdf = cumsum (:39); inds = searchsorted(cdf, u,
+    right=True) clamped to [0, n-1] (:41,44); the new depths are NOT drawn inside the selected bins: they index a
+    single shared vector samples = samples01*(tf-tn)+tn (:43,45); merged with t and sorted (:46-47).
+    Returns (points [R, S+n, 3], t_fine [R, S+n])."""
+    w = weights.reshape(weights.shape[0], -1).clone()
+    w[w < 0] = 0
+    pdf = (w + 1e-5) / torch.sum(w + 1e-5, dim=-1, keepdim=True)
+    cdf = torch.cumsum(pdf, dim=-1)
+    inds = torch.searchsorted(cdf, u01.contiguous(), right=True).clamp(0, n_samples - 1)
+    smp = (samples01 * (tf - tn) + tn)[inds]
+    tt, _ = torch.sort(torch.cat([t.expand(inds.shape[0], t.shape[-1]), smp], dim=-1), dim=-1)
+    return o[..., None, :] + d[..., None, :] * tt[..., :, None], tt
+
+
+def composite_per_ray(t2: torch.Tensor, rgb: torch.Tensor, sigma: torch.Tensor, dir_norm):
+    """calc_color with a per-ray t [R,S] (helper.py:65-71 handles both ranks)."""
+    delta = torch.zeros_like(t2)
+    delta[:, :-1] = t2[:, 1:] - t2[:, :-1]
+    delta = delta * dir_norm
+    sig = torch.where(sigma >= -10, sigma, torch.full_like(sigma, -10.0))
+    p = sig * delta
+    alpha = 1 - torch.exp(-p)
+    Tr = torch.exp(-torch.cumsum(p, dim=-1))
+    Tr = torch.cat([torch.ones_like(Tr[:, :1]), Tr[:, :-1]], dim=-1)
+    w = Tr * alpha
+    return (w[:, :, None] * rgb).sum(dim=-2), w[:, :, None]
+
+
+def render_hierarchical(o, d, t, dir_norm, tables, scales, mu, sigma, mlp_params, u01, samples01, tn=2.0, tf=6.0, num_freq=4):
+    """vol_render(hierarchical=True): coarse pass, resample, fine pass on S+S sorted depths.  Returns (Cr, Cf)."""
+    R, S = o.shape[0], t.shape[0]
+    pts = sample_points(o, d, t).reshape(-1, 3)
+    feat = hash_encode(pts, tables, scales, mu, sigma)
+    pe = dir_encode(d[:, None, :].expand(R, S, 3).reshape(-1, 3), num_freq)
+    out = mlp_forward(feat, pe, mlp_params)
+    Cr, wts = composite(t, out[:, 0:3].reshape(R, S, 3), out[:, 3].reshape(R, S), dir_norm)
+    pts_f, t_f = hierarchical_sample(o, d, t, wts.detach(), S, tn, tf, u01, samples01)
+    S2 = t_f.shape[1]
+    feat_f = hash_encode(pts_f.reshape(-1, 3), tables, scales, mu, sigma)
+    pe_f = dir_encode(d[:, None, :].expand(R, S2, 3).reshape(-1, 3), num_freq)
+    out_f = mlp_forward(feat_f, pe_f, mlp_params)
+    Cf, _ = composite_per_ray(t_f, out_f[:, 0:3].reshape(R, S2, 3), out_f[:, 3].reshape(R, S2), dir_norm)
+    return Cr, Cf

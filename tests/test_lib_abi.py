@@ -48,7 +48,9 @@ def test_argument_validation_without_gpu(L):
     # too many levels
     assert lib.hbr_hash_encode_fwd(8, None, None, None, 4, 1, 8, sc, mu, 1.0, 33, 1024, 2, 8, 1, 0, 0, None) == -1
     # S > 4096 unsupported by the one-wave-per-ray compositor
-    assert lib.hbr_composite_fwd(8, 8, 3, 8, 1, None, 4, 5000, 8, None, None) == -2
+    assert lib.hbr_composite_fwd(8, 0, 8, 3, 8, 1, None, 4, 5000, 8, None, None) == -2
+    # per-ray t stride shorter than S
+    assert lib.hbr_composite_fwd(8, 3, 8, 3, 8, 1, None, 4, 16, 8, None, None) == -1
     # workspace too small
     assert lib.hbr_mlp_fwd(16, 0, 32, 0, 16, 4, 1, 16, 1, 16, 16, 10, None) == -4
     # adam: misaligned pointer

@@ -187,3 +187,26 @@ def test_g8_full_render_and_train_step():
 def test_g10_psnr():
     g = load_golden("g10_psnr.npz")
     assert np.allclose(ref_cpu.psnr(T_(g["a"]), T_(g["b"])).numpy(), g["psnr"], rtol=1e-6)
+
+
+def test_g12_hierarchical_sampler_and_render():
+    g = load_golden("g12_hierarchical.npz")
+    g8 = load_golden("g8_render_step.npz")
+    o, d, dn, gt, t = (T_(g8[k]) for k in ("o", "d", "dir_norm", "gt", "t"))
+    S = t.shape[0]
+    pts, tf_ = ref_cpu.hierarchical_sample(o, d, t, T_(g["hs_weights"]), S, 2.0, 6.0, T_(g["hs_u"]), T_(g["hs_samples01"]))
+    assert np.array_equal(tf_.numpy(), g["hs_t"])           # same bins, same sort: exact
+    assert np.allclose(pts.numpy(), g["hs_rays"], atol=1e-6)
+    assert tf_.shape[1] == 2 * S and bool((tf_[:, 1:] >= tf_[:, :-1]).all())
+    tabs, params, scales = _g8_state(g8)
+    mu, sigma = T_(g8["mu"]), torch.tensor(float(g8["sigma"]))
+    Cr, Cf = ref_cpu.render_hierarchical(o, d, t, dn, tabs, scales, mu, sigma, params, T_(g["u"]), T_(g["samples01"]))
+    assert np.allclose(Cr.detach().numpy(), g["Cr"], rtol=1e-4, atol=1e-5)
+    assert np.allclose(Cf.detach().numpy(), g["Cf"], rtol=1e-4, atol=1e-5)
+    loss = torch.mean((Cr - gt) ** 2) + torch.mean((Cf - gt) ** 2)
+    assert abs(loss.item() - float(g["loss"])) <= 1e-5 * float(g["loss"])
+    loss.backward()
+    got = np.stack([x.grad.numpy() for x in tabs])
+    assert np.allclose(got, g["dtables"], rtol=1e-3, atol=1e-5 * np.abs(g["dtables"]).max())
+    for k, p in params.items():
+        assert np.allclose(p.grad.numpy(), g["g." + k], rtol=1e-3, atol=1e-5 * np.abs(g["g." + k]).max()), k
