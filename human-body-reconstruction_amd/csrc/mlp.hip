@@ -444,9 +444,12 @@ __device__ __host__ constexpr int dw_tile_base(int l) {
 constexpr int kDwBytes = kDwTiles * 16 * 64 * 4;
 constexpr int kDbBytes = NLAYER * 64 * 4;
 
-// orientation-2 fragments of a tensor given its orientation-1 fragments: xt[tile][s'] (k = points)
-template <class P, int NT, int NK>
-__device__ __forceinline__ void transpose_frags(const typename P::frag (&x)[NK], int lane, typename P::frag (&xt)[NT][P::S32]) {
+// orientation-2 fragments of a tensor given its orientation-1 fragments: xt[tile][s'] (k = points).
+// `colsum[t]` (optional) receives the lane's sum over its 16 point registers of tile t, taken from the fp32 tile
+// before it is re-packed - the bias gradient, without unpacking bf16 again.
+template <class P, int NT, int NK, bool SUM>
+__device__ __forceinline__ void transpose_frags(const typename P::frag (&x)[NK], int lane, typename P::frag (&xt)[NT][P::S32],
+                                                float* colsum = nullptr) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     f32x16 acc;
@@ -455,6 +458,11 @@ __device__ __forceinline__ void transpose_frags(const typename P::frag (&x)[NK],
 #pragma unroll
     for (int s = 0; s < P::S32; ++s) {
       if (t * P::S32 + s < NK) acc = P::mfma(x[t * P::S32 + s], P::ident(s, lane), acc);
+    }
+    if (SUM) {
+      float a = (acc[0] + acc[1]) + (acc[2] + acc[3]), b = (acc[4] + acc[5]) + (acc[6] + acc[7]);
+      float c = (acc[8] + acc[9]) + (acc[10] + acc[11]), d = (acc[12] + acc[13]) + (acc[14] + acc[15]);
+      colsum[t] += (a + b) + (c + d);
     }
 #pragma unroll
     for (int s = 0; s < P::S32; ++s) xt[t][s] = P::from_acc(acc, s);
@@ -487,28 +495,6 @@ __device__ __forceinline__ void wgrad(DwAcc& A, const typename P::frag (&xt)[NIN
         A.t[dw_tile_base(LAYER) + n * NOUT + m] = P::mfma(xt[n][s], dzt[m][s], A.t[dw_tile_base(LAYER) + n * NOUT + m]);
     }
   }
-}
-
-// bias gradient: sum of the orientation-2 dZ tile over its 16 point registers (the two lane halves meet in LDS)
-template <class P>
-__device__ __forceinline__ float frag_sum(const typename P::frag (&f)[P::S32]) {
-  float s = 0.f;
-  if constexpr (P::ELEMS == 8) {
-#pragma unroll
-    for (int k = 0; k < P::S32; ++k)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s += (float)f[k][j];
-  } else {
-#pragma unroll
-    for (int k = 0; k < P::S32; ++k) s += f[k];
-  }
-  return s;
-}
-
-template <class P, int LAYER, int NOUT>
-__device__ __forceinline__ void bgrad(DwAcc& A, const typename P::frag (&dzt)[NOUT][P::S32]) {
-#pragma unroll
-  for (int m = 0; m < NOUT; ++m) A.b[db_base(LAYER) + m] += frag_sum<P>(dzt[m]);
 }
 
 struct DFeatDst {
@@ -585,10 +571,9 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(const char* __rest
     }
     if (wC3) {
       typename P::frag xt[2][P::S32], zt[1][P::S32];
-      transpose_frags<P, 2, 2 * P::S32>(sv.c2, lane, xt);
-      transpose_frags<P, 1, P::S8>(dz3, lane, zt);
+      transpose_frags<P, 2, 2 * P::S32, false>(sv.c2, lane, xt);
+      transpose_frags<P, 1, P::S8, true>(dz3, lane, zt, A.b + db_base(C3));
       wgrad<P, C3, 2, 1>(A, xt, zt);
-      bgrad<P, C3, 1>(A, zt);
     }
     if (needC2) {
       // ---- C2
@@ -599,10 +584,9 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(const char* __rest
         mask_frags<P, 2>(a, sv.mc2, dzc2);
         if (wC2) {
           typename P::frag xt[2][P::S32], zt[2][P::S32];
-          transpose_frags<P, 2, 2 * P::S32>(sv.c1, lane, xt);
-          transpose_frags<P, 2, 2 * P::S32>(dzc2, lane, zt);
+          transpose_frags<P, 2, 2 * P::S32, false>(sv.c1, lane, xt);
+          transpose_frags<P, 2, 2 * P::S32, true>(dzc2, lane, zt, A.b + db_base(C2));
           wgrad<P, C2, 2, 2>(A, xt, zt);
-          bgrad<P, C2, 2>(A, zt);
         }
       }
       if (needC1) {
@@ -614,10 +598,9 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(const char* __rest
           mask_frags<P, 2>(a, sv.mc1, dzc1);
           if (wC1) {
             typename P::frag xt[2][P::S32], zt[2][P::S32];
-            transpose_frags<P, 2, P::S32 + P::S8>(sv.cin, lane, xt);
-            transpose_frags<P, 2, 2 * P::S32>(dzc1, lane, zt);
+            transpose_frags<P, 2, P::S32 + P::S8, false>(sv.cin, lane, xt);
+            transpose_frags<P, 2, 2 * P::S32, true>(dzc1, lane, zt, A.b + db_base(C1));
             wgrad<P, C1, 2, 2>(A, xt, zt);
-            bgrad<P, C1, 2>(A, zt);
           }
         }
         if (needL3) {
@@ -631,10 +614,9 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(const char* __rest
             for (int s = 0; s < P::S16; ++s) dz_s[s] = P::from_acc(a[0], s);
             if (wL3) {
               typename P::frag xt[2][P::S32], zt[1][P::S32];
-              transpose_frags<P, 2, 2 * P::S32>(sv.h2, lane, xt);
-              transpose_frags<P, 1, P::S16>(dz_s, lane, zt);
+              transpose_frags<P, 2, 2 * P::S32, false>(sv.h2, lane, xt);
+              transpose_frags<P, 1, P::S16, true>(dz_s, lane, zt, A.b + db_base(L3));
               wgrad<P, L3, 2, 1>(A, xt, zt);
-              bgrad<P, L3, 1>(A, zt);
             }
           }
           if (needL2) {
@@ -646,10 +628,9 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(const char* __rest
               mask_frags<P, 2>(a, sv.m2, dz2);
               if (wL2) {
                 typename P::frag xt[2][P::S32], zt[2][P::S32];
-                transpose_frags<P, 2, 2 * P::S32>(sv.h1, lane, xt);
-                transpose_frags<P, 2, 2 * P::S32>(dz2, lane, zt);
+                transpose_frags<P, 2, 2 * P::S32, false>(sv.h1, lane, xt);
+                transpose_frags<P, 2, 2 * P::S32, true>(dz2, lane, zt, A.b + db_base(L2));
                 wgrad<P, L2, 2, 2>(A, xt, zt);
-                bgrad<P, L2, 2>(A, zt);
               }
             }
             if (needL1) {
@@ -660,10 +641,9 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(const char* __rest
                 dense<P, 2, 2 * P::S32, false>(img, T::b_base(L2), nullptr, lane, lofs, dz2, a);
                 mask_frags<P, 2>(a, sv.m1, dz1);
                 typename P::frag xt[1][P::S32], zt[2][P::S32];
-                transpose_frags<P, 1, P::S32>(sv.x0, lane, xt);
-                transpose_frags<P, 2, 2 * P::S32>(dz1, lane, zt);
+                transpose_frags<P, 1, P::S32, false>(sv.x0, lane, xt);
+                transpose_frags<P, 2, 2 * P::S32, true>(dz1, lane, zt, A.b + db_base(L1));
                 wgrad<P, L1, 1, 2>(A, xt, zt);
-                bgrad<P, L1, 2>(A, zt);
               }
               // ---- d feat
               if (dfd.p) {
