@@ -5,11 +5,13 @@ MLP with the fixed view direction (0,0,1) (nerf2mesh.py:69-70) and stores `[res,
 (:85-87) for `torchmcubes.marching_cubes(density, 30.0)` (third-party, out of scope).  Here the query re-uses K1 and
 K3 unchanged (planar features, one encoded direction row shared by every point of a batch).
 
-Quirk reproduced: coordinates are built in float16 (nerf2mesh.py:40) and cast to fp32 before encoding, so the grid
-points are the fp16-rounded positions, not the exact lattice.
+Quirks reproduced: coordinates are built in float64, laid out by `np.meshgrid`'s default 'xy' indexing and cast to
+float16 (nerf2mesh.py:30-40), so the grid points are fp16-rounded positions in (y, x, z)-major order; the view
+direction is float16 too, so its sin/cos encoding is rounded to float16.
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 from . import ops
@@ -18,11 +20,18 @@ from .hash_encoding import HashEncoder
 from .test_hash import MLP_3D
 
 
-def grid_coordinates(min_bound: torch.Tensor, max_bound: torch.Tensor, res: int, device) -> torch.Tensor:
-    """[res^3, 3] fp32 values of fp16-rounded lattice points, x slowest / z fastest ('ij' meshgrid, nerf2mesh.py:36-41)."""
-    axes = [torch.linspace(float(min_bound[i]), float(max_bound[i]), res, device=device).to(torch.float16) for i in range(3)]
-    gx, gy, gz = torch.meshgrid(*axes, indexing="ij")
-    return torch.stack([gx, gy, gz], dim=-1).reshape(-1, 3).float()
+def grid_coordinates(min_bound, max_bound, res: int, device) -> torch.Tensor:
+    """[res^3, 3] fp32 values of the fp16-rounded lattice, in the reference's order (nerf2mesh.py:30-40):
+    float64 `np.linspace` per axis, `np.meshgrid(x, y, z)` with its default 'xy' indexing (so the flat index is
+    (iy*res + ix)*res + iz), stacked, cast to float16."""
+    mn = np.asarray(torch.as_tensor(min_bound).cpu(), dtype=np.float64) if not isinstance(min_bound, np.ndarray) else min_bound
+    mx = np.asarray(torch.as_tensor(max_bound).cpu(), dtype=np.float64) if not isinstance(max_bound, np.ndarray) else max_bound
+    x = np.linspace(mn[0], mx[0], res)
+    y = np.linspace(mn[1], mx[1], res)
+    z = np.linspace(mn[2], mx[2], res)
+    X, Y, Z = np.meshgrid(x, y, z)
+    grid = torch.stack([torch.tensor(X.reshape(-1)), torch.tensor(Y.reshape(-1)), torch.tensor(Z.reshape(-1))], dim=1)
+    return grid.to(torch.float16).to(device).float()
 
 
 @torch.no_grad()
@@ -36,7 +45,9 @@ def query_density_grid(encoder: HashEncoder, mlp: MLP_3D, min_bound, max_bound, 
     flat, _ = mlp.flat_params()
     prec = ops.precision_from_autocast() if precision is None else precision
     pts = grid_coordinates(min_bound, max_bound, res, dev)
-    pe = ops.dir_encode(torch.tensor([view_dir], dtype=torch.float32, device=dev), num_freq)  # [1,24], shared by all points
+    # the reference feeds a float16 view_dir through PositionalEncoder (nerf2mesh.py:69-70,81): sin/cos come out as
+    # float16 and are promoted back to fp32 by the concat in MLP_3D.forward
+    pe = ops.dir_encode(torch.tensor([view_dir], dtype=torch.float32, device=dev), num_freq).half().float().contiguous()
     out = torch.empty((pts.shape[0], 4), dtype=torch.float32, device=out_device or dev)
     for i in range(0, pts.shape[0], batch):
         x = pts[i:i + batch].contiguous()

@@ -518,7 +518,9 @@ def test_dense_grid_query_matches_oracle():
     prm = {k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("p.")}
     sc = ref_cpu.level_scales(16, 2048.0, int(g["L"]))
     feat = ref_cpu.hash_encode(pts, tabs, sc, mn, torch.tensor(float(g["sigma"])))
-    pe = ref_cpu.dir_encode(torch.tensor([[0.0, 0.0, 1.0]]), 4).expand(pts.shape[0], 24)
+    pe = ref_cpu.dir_encode(torch.tensor([[0.0, 0.0, 1.0]]), 4).half().float().expand(pts.shape[0], 24)
+    # np.meshgrid 'xy' order: flat index (iy*res + ix)*res + iz
+    assert pts[1, 2] > pts[0, 2] and pts[res, 0] > pts[0, 0] and pts[res * res, 1] > pts[0, 1]
     ref = ref_cpu.mlp_forward(feat, pe, prm).reshape(res, res, res, 4)
     assert torch.allclose(grid.cpu(), ref, rtol=1e-4, atol=1e-5)
 
@@ -615,3 +617,65 @@ def test_train_script_synthetic_smoke(tmp_path, monkeypatch):
     assert (tmp_path / "bounds_model.npy").exists()
     r2 = train_hash2.main(common + ["--steps", "3", "--hierarchical", "--precision", "fp32"])
     assert r2["steps"] == 3 and np.isfinite(r2["loss"])
+
+
+def test_bf16_feature_buffer_pipeline():
+    """feat_dtype=BF16: K1 writes the planar features as bf16 (round-to-nearest-even), K3/K4 read them and K4 writes a
+    bf16 d feat that K2 scatters.  In bf16 MLP mode the forward is bit-identical to the fp32-feature pipeline (the MLP
+    rounds its inputs to bf16 either way); the table gradient differs only by the bf16 rounding of d feat."""
+    from hbr_amd._lib import BF16, F32
+    from hbr_amd.trainer import HashNeRFTrainer, build_default_model
+    o0, d0, _, _ = ref_cpu.synthetic_rays(4096, seed=0)
+    mn, mx, sig = ref_cpu.bbox_mu_sigma(o0, d0)
+    R, S = 1000, 48  # N = 48000: ragged against the 32-point MLP tile, the 256-thread K1 tile and the 1024-point K2 stripe
+    batch = tuple(a.to(DEV) for a in ref_cpu.synthetic_rays(R, seed=5))
+    tt = ref_cpu.strat_jitter_to_t(2.0, 6.0, S, torch.rand(S, generator=torch.Generator().manual_seed(3))).to(DEV)
+    out = {}
+    for fdt in (F32, BF16):
+        enc, denc, mlp = build_default_model(mn, sig, DEV, T=2 ** 14, seed=0)
+        with torch.no_grad():
+            enc.stacked_tables().uniform_(-0.5, 0.5, generator=torch.Generator(device=DEV).manual_seed(1))
+        tr = HashNeRFTrainer(enc, mlp, num_samples=S, total_steps=10, precision=BF16, feat_dtype=fdt, scatter_algo=2)
+        C0 = tr.render(batch[0], batch[1], batch[2], t=tt)
+        loss = tr.step(*batch, t=tt)
+        out[fdt] = (C0, float(loss), tr.g_tab.clone(), tr.g_mlp.clone())
+    assert torch.equal(out[F32][0], out[BF16][0])            # identical rendered colours
+    assert abs(out[F32][1] - out[BF16][1]) < 1e-6 * abs(out[F32][1]) + 1e-12
+    gt_f, gt_b = out[F32][2], out[BF16][2]
+    assert float((gt_f - gt_b).norm() / gt_f.norm()) < 1e-2   # bf16 d feat: 2^-9 relative per contribution
+    assert torch.equal(gt_f != 0, gt_b != 0)
+    assert float((out[F32][3] - out[BF16][3]).norm() / out[F32][3].norm()) < 1e-5  # MLP grads do not see d feat's dtype
+
+
+def test_edge_shapes():
+    """Single ray, S = 1 and S just over a 64-lane chunk; one point; T = 2 (every corner collides)."""
+    from hbr_amd import ops
+    from hbr_amd._lib import PLANAR, ROWS
+    sc = ref_cpu.level_scales(16, 2048.0, 16)
+    rng = np.random.default_rng(61)
+    for R, S, T in ((1, 1, 2), (1, 65, 64), (3, 130, 2 ** 12)):
+        o, d, dn, _ = ref_cpu.synthetic_rays(R, seed=R + S)
+        mn, mx, sig = ref_cpu.bbox_mu_sigma(*ref_cpu.synthetic_rays(64, seed=1)[:2])
+        geom = ops.HashGeom(tuple(float(v) for v in sc), tuple(float(v) for v in mn), float(sig), T, 2)
+        tab = rng.uniform(-1, 1, (16, T, 2)).astype(np.float32)
+        t = torch.from_numpy(np.sort(rng.uniform(2, 6, S)).astype(np.float32))
+        pts = ref_cpu.sample_points(o, d, t).reshape(-1, 3)
+        y_ref = ref_cpu.hash_encode(pts, [torch.from_numpy(tab[l]) for l in range(16)], sc, mn, sig)
+        y = ops.hash_encode_fwd(geom, T_(tab), rays=(o.to(DEV), d.to(DEV), t.to(DEV)), layout=ROWS).cpu()
+        assert torch.allclose(y, y_ref, rtol=0, atol=1e-6 * float(y_ref.abs().max()) + 1e-9), (R, S, T)
+        dy = torch.from_numpy(rng.standard_normal(y_ref.shape).astype(np.float32))
+        g_ref = ref_cpu.hash_encode_backward(pts, dy, sc, mn, sig, T)
+        for algo in (1, 2):
+            dt = torch.zeros((16, T, 2), device=DEV)
+            ops.hash_encode_bwd(geom, dy.to(DEV), dt, rays=(o.to(DEV), d.to(DEV), t.to(DEV)), layout=ROWS, algo=algo)
+            assert torch.allclose(dt.cpu(), g_ref, rtol=1e-4, atol=1e-5 * float(g_ref.abs().max())), (R, S, T, algo)
+        # MLP + composite on the same ragged sizes
+        prm = ref_cpu.mlp_init(9)
+        P = T_(np.concatenate([v.numpy().reshape(-1) for v in prm.values()]))
+        pe = ops.dir_encode(d.to(DEV), 4)
+        out = ops.mlp_fwd(y.to(DEV), ROWS, pe, S, P, 0)
+        ref = ref_cpu.mlp_forward(y_ref, ref_cpu.dir_encode(d, 4)[:, None, :].expand(R, S, 24).reshape(-1, 24), prm)
+        assert torch.allclose(out.cpu(), ref, rtol=1e-4, atol=1e-5)
+        Cr, _ = ops.CompositeFn.apply(t.to(DEV), out[:, :3].reshape(R, S, 3).contiguous(), out[:, 3].reshape(R, S).contiguous(), dn.to(DEV))
+        Cr_ref, _ = ref_cpu.composite(t, ref[:, :3].reshape(R, S, 3), ref[:, 3].reshape(R, S), dn)
+        assert torch.allclose(Cr.cpu(), Cr_ref, rtol=1e-4, atol=1e-5)
