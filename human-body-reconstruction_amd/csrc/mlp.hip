@@ -76,6 +76,14 @@ struct PBf16 {
   __device__ static __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
+  // accumulate into a tile that lives in the accumulator (AGPR) half of the register file for the whole kernel.
+  // Inline asm because the build forces the VGPR form on the builtin MFMAs (the chain's results are read by VALU code
+  // right away); these dW tiles are only ever touched by the next MFMA, so keeping them in AGPRs costs no moves.
+  // `s_nop 1`: wait states between the VALU (v_cvt_pk) writes of a/b and an MFMA reading them, which hipcc does not
+  // insert inside an asm statement (cdna_hip_programming.md 5.7 item 2).
+  __device__ static __forceinline__ void mfma_acc(frag a, frag b, f32x16& c) {
+    asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  }
   __device__ static __forceinline__ frag from_acc(const f32x16& acc, int s) {
     frag f;
 #pragma unroll
@@ -120,6 +128,9 @@ struct PF32 {
   __device__ __host__ static constexpr int rho(int s, int h, int) { return acc_row(s, h); }
   __device__ static __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+  __device__ static __forceinline__ void mfma_acc(frag a, frag b, f32x16& c) {
+    asm("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
   }
   __device__ static __forceinline__ frag from_acc(const f32x16& acc, int s) { return acc[s]; }
   __device__ static __forceinline__ frag zero() { return 0.f; }
@@ -492,7 +503,7 @@ __device__ __forceinline__ void wgrad(DwAcc& A, const typename P::frag (&xt)[NIN
     for (int m = 0; m < NOUT; ++m) {
 #pragma unroll
       for (int s = 0; s < P::S32; ++s)
-        A.t[dw_tile_base(LAYER) + n * NOUT + m] = P::mfma(xt[n][s], dzt[m][s], A.t[dw_tile_base(LAYER) + n * NOUT + m]);
+        P::mfma_acc(xt[n][s], dzt[m][s], A.t[dw_tile_base(LAYER) + n * NOUT + m]);
     }
   }
 }
@@ -681,6 +692,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(const char* __rest
     }
   }
 
+  asm volatile("s_nop 15" ::: "memory");  // last asm MFMA's D -> first non-MFMA reader (12 wait states, 5.7 item 2)
   // ---- each wave adds its register accumulators to the workgroup image once (ds_add_f32, off the hot loop)
 #pragma unroll
   for (int l = 0; l < NLAYER; ++l) {
