@@ -254,28 +254,41 @@ __device__ __forceinline__ void dense(const char* img, int fbase, const float* b
   }
 }
 
+// ReLU + re-pack.  No mask is recorded: the backward pass reads the sign back from the packed activations themselves
+// (a ReLU output is > 0 exactly where its bits are non-zero), which saves three VALU ops per element in the forward.
 template <class P, int NT>
-__device__ __forceinline__ void relu_frags(f32x16 (&acc)[NT], uint32_t& mask, typename P::frag (&out)[NT * P::S32]) {
-  mask = 0;
+__device__ __forceinline__ void relu_frags(f32x16 (&acc)[NT], typename P::frag (&out)[NT * P::S32]) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const bool pos = acc[t][q] > 0.f;
-      mask |= pos ? (1u << (t * 16 + q)) : 0u;
-      acc[t][q] = pos ? acc[t][q] : 0.f;
-    }
+    for (int q = 0; q < 16; ++q) acc[t][q] = fmaxf(acc[t][q], 0.f);
 #pragma unroll
     for (int s = 0; s < P::S32; ++s) out[t * P::S32 + s] = P::from_acc(acc[t], s);
   }
 }
 
+// dZ = dX where the forward activation h was positive, else 0; then re-pack
 template <class P, int NT>
-__device__ __forceinline__ void mask_frags(f32x16 (&acc)[NT], uint32_t mask, typename P::frag (&out)[NT * P::S32]) {
+__device__ __forceinline__ void mask_frags(f32x16 (&acc)[NT], const typename P::frag (&h)[NT * P::S32],
+                                           typename P::frag (&out)[NT * P::S32]) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[t][q] = ((mask >> (t * 16 + q)) & 1u) ? acc[t][q] : 0.f;
+    for (int s = 0; s < P::S32; ++s) {
+      if constexpr (P::ELEMS == 8) {
+        // a ReLU output is positive exactly where its bf16 bits are non-zero; test the packed pairs directly
+        // (a per-element __builtin_bit_cast<uint16_t>(h[..][j]) test gave wrong masks with hipcc 7.2 - keep the u32 form)
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 hw = __builtin_bit_cast(u32x4, h[t * P::S32 + s]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          acc[t][8 * s + 2 * k] = (hw[k] & 0xffffu) ? acc[t][8 * s + 2 * k] : 0.f;
+          acc[t][8 * s + 2 * k + 1] = (hw[k] > 0xffffu) ? acc[t][8 * s + 2 * k + 1] : 0.f;
+        }
+      } else {
+        acc[t][s] = (h[t * P::S32 + s] > 0.f) ? acc[t][s] : 0.f;
+      }
+    }
 #pragma unroll
     for (int s = 0; s < P::S32; ++s) out[t * P::S32 + s] = P::from_acc(acc[t], s);
   }
@@ -357,7 +370,6 @@ struct Saved {
   typename P::frag cin[P::S32 + P::S8];
   typename P::frag c1[2 * P::S32];
   typename P::frag c2[2 * P::S32];
-  uint32_t m1, m2, mc1, mc2;
   float s0;            // raw density (row 0 of the L3 tile; meaningful on h == 0 lanes)
   float raw[3];        // raw rgb (rows 0..2 of the C3 tile; h == 0 lanes)
 };
@@ -373,12 +385,12 @@ __device__ __forceinline__ void forward_tile(const char* img, const float* bias,
   {
     f32x16 a[2];
     dense<P, 2, P::S32, true>(img, T::f_base(L1), bias + 64 * L1, lane, lofs, sv.x0, a);
-    relu_frags<P, 2>(a, sv.m1, sv.h1);
+    relu_frags<P, 2>(a, sv.h1);
   }
   {
     f32x16 a[2];
     dense<P, 2, 2 * P::S32, true>(img, T::f_base(L2), bias + 64 * L2, lane, lofs, sv.h1, a);
-    relu_frags<P, 2>(a, sv.m2, sv.h2);
+    relu_frags<P, 2>(a, sv.h2);
   }
   {
     f32x16 a[1];
@@ -389,12 +401,12 @@ __device__ __forceinline__ void forward_tile(const char* img, const float* bias,
   {
     f32x16 a[2];
     dense<P, 2, P::S32 + P::S8, true>(img, T::f_base(C1), bias + 64 * C1, lane, lofs, sv.cin, a);
-    relu_frags<P, 2>(a, sv.mc1, sv.c1);
+    relu_frags<P, 2>(a, sv.c1);
   }
   {
     f32x16 a[2];
     dense<P, 2, 2 * P::S32, true>(img, T::f_base(C2), bias + 64 * C2, lane, lofs, sv.c1, a);
-    relu_frags<P, 2>(a, sv.mc2, sv.c2);
+    relu_frags<P, 2>(a, sv.c2);
   }
   {
     f32x16 a[1];
@@ -592,7 +604,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(const char* __rest
       {
         f32x16 a[2];
         dense<P, 2, P::S8, false>(img, T::b_base(C3), nullptr, lane, lofs, dz3, a);
-        mask_frags<P, 2>(a, sv.mc2, dzc2);
+        mask_frags<P, 2>(a, sv.c2, dzc2);
         if (wC2) {
           typename P::frag xt[2][P::S32], zt[2][P::S32];
           transpose_frags<P, 2, 2 * P::S32, false>(sv.c1, lane, xt);
@@ -606,7 +618,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(const char* __rest
         {
           f32x16 a[2];
           dense<P, 2, 2 * P::S32, false>(img, T::b_base(C2), nullptr, lane, lofs, dzc2, a);
-          mask_frags<P, 2>(a, sv.mc1, dzc1);
+          mask_frags<P, 2>(a, sv.c1, dzc1);
           if (wC1) {
             typename P::frag xt[2][P::S32], zt[2][P::S32];
             transpose_frags<P, 2, P::S32 + P::S8, false>(sv.cin, lane, xt);
@@ -636,7 +648,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(const char* __rest
             {
               f32x16 a[2];
               dense<P, 2, P::S16, false>(img, T::b_base(L3), nullptr, lane, lofs, dz_s, a);
-              mask_frags<P, 2>(a, sv.m2, dz2);
+              mask_frags<P, 2>(a, sv.h2, dz2);
               if (wL2) {
                 typename P::frag xt[2][P::S32], zt[2][P::S32];
                 transpose_frags<P, 2, 2 * P::S32, false>(sv.h1, lane, xt);
@@ -650,7 +662,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(const char* __rest
               {
                 f32x16 a[2];
                 dense<P, 2, 2 * P::S32, false>(img, T::b_base(L2), nullptr, lane, lofs, dz2, a);
-                mask_frags<P, 2>(a, sv.m1, dz1);
+                mask_frags<P, 2>(a, sv.h1, dz1);
                 typename P::frag xt[1][P::S32], zt[2][P::S32];
                 transpose_frags<P, 1, P::S32, false>(sv.x0, lane, xt);
                 transpose_frags<P, 2, 2 * P::S32, true>(dz1, lane, zt, A.b + db_base(L1));
