@@ -458,7 +458,7 @@ __global__ __launch_bounds__(kFwdWaves * 64) void mlp_fwd_kernel(const char* __r
 // ------------------------------------------------------------------------------------------------
 constexpr int kDwTiles = 18;  // L1:2 L2:4 L3:2 C1:4 C2:4 C3:2
 #ifndef HBR_BWD_SPLIT
-#define HBR_BWD_SPLIT 2  // number of bf16 backward launches (2: one wave/SIMD; 3: two waves/SIMD)
+#define HBR_BWD_SPLIT 0  // 0: single pass with shared dW tiles (mlp_bwd_fused_kernel); 2/3: per-wave dW tiles, 2 or 3 launches
 #endif
 __device__ __host__ constexpr int dw_tile_base(int l) {
   constexpr int b[NLAYER] = {0, 2, 6, 8, 12, 16};
@@ -746,6 +746,225 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(const char* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// backward kernel, single pass: the four waves of a workgroup SHARE the weight-gradient accumulators
+// ------------------------------------------------------------------------------------------------
+// mlp_bwd_kernel above needs two launches because one wave cannot hold all 18 dW tiles (288 registers) next to its
+// working set.  Here every wave still runs the whole chain for its own 32-point tile, but owns only ONE dW tile per
+// layer (<= 6 tiles = 96 accumulator registers): after transposing a layer's X and dZ fragments it parks them in an
+// LDS exchange slot, the workgroup meets at a barrier, and each wave accumulates ITS tile of that layer over the
+// fragments of all four waves (K = 128 points per round).  Layers with four dW tiles give one tile to every wave;
+// layers with two give them to waves {0,1} (C3, L1) or {2,3} (L3).  The exchange buffer is double-buffered, so one
+// barrier per layer suffices: a wave can only overwrite buffer b two layers later, after the next barrier, which
+// every wave reaches only after finishing its reads of b.  No LDS atomics, no second recompute of the forward.
+template <class P>
+struct Xch {
+  static constexpr int FRAG_B = (int)sizeof(typename P::frag) * 64;
+  static constexpr int SLOT_FRAGS = 4 * P::S32;  // XT tiles 0,1 then dZT tiles 0,1, S32 k-steps (of points) each
+  static constexpr int SLOT_B = SLOT_FRAGS * FRAG_B;
+  static constexpr int BUF_B = 4 * SLOT_B;       // four waves
+  static constexpr int BYTES = 2 * BUF_B;
+};
+
+template <class P, int LAYER, int NIN, int NOUT, int NKX, int NKZ>
+__device__ __forceinline__ void exchange_wgrad(char* xch, int& buf, int lane, int wv, const typename P::frag (&x)[NKX],
+                                               const typename P::frag (&dz)[NKZ], f32x16& acc, float* colsum) {
+  using X = Xch<P>;
+  typename P::frag xt[NIN][P::S32], zt[NOUT][P::S32];
+  transpose_frags<P, NIN, NKX, false>(x, lane, xt);
+  transpose_frags<P, NOUT, NKZ, true>(dz, lane, zt, colsum);
+  char* mine = xch + buf * X::BUF_B + wv * X::SLOT_B + lane * (int)sizeof(typename P::frag);
+#pragma unroll
+  for (int n = 0; n < NIN; ++n)
+#pragma unroll
+    for (int s = 0; s < P::S32; ++s) *(typename P::frag*)(mine + (n * P::S32 + s) * X::FRAG_B) = xt[n][s];
+#pragma unroll
+  for (int m = 0; m < NOUT; ++m)
+#pragma unroll
+    for (int s = 0; s < P::S32; ++s) *(typename P::frag*)(mine + ((2 + m) * P::S32 + s) * X::FRAG_B) = zt[m][s];
+  __syncthreads();
+  // which dW^T tile [in tile n][out tile m] of this layer is mine
+  constexpr int tiles = NIN * NOUT;
+  const int first = (tiles == 4 || LAYER == C3 || LAYER == L1) ? 0 : 2;
+  const int tau = wv - first;
+  if (tau >= 0 && tau < tiles) {  // wave-uniform
+    const int n = tau / NOUT, m = tau % NOUT;
+    const char* base = xch + buf * X::BUF_B + lane * (int)sizeof(typename P::frag);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+#pragma unroll
+      for (int s = 0; s < P::S32; ++s) {
+        const typename P::frag a = *(const typename P::frag*)(base + w * X::SLOT_B + (n * P::S32 + s) * X::FRAG_B);
+        const typename P::frag b = *(const typename P::frag*)(base + w * X::SLOT_B + ((2 + m) * P::S32 + s) * X::FRAG_B);
+        P::mfma_acc(a, b, acc);
+      }
+    }
+  }
+  buf ^= 1;
+}
+
+template <class P, int LAYOUT, int DT, bool WLDS>
+__global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restrict__ gimg, FeatSrc fs, PeSrc ps,
+                                                            const float* __restrict__ dout, DFeatDst dfd,
+                                                            float* __restrict__ dparams) {
+  using T = Tab<P>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* xch = smem;
+  char* limg = smem + Xch<P>::BYTES;
+  if (WLDS) stage_image(limg, gimg, T::IMG_BYTES);
+  __syncthreads();
+  const char* img = WLDS ? (const char*)limg : gimg;
+  const float* bias = (const float*)(img + T::BIAS_OFF_ALL);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5;
+  const uint32_t ntiles = (fs.N + 31) / 32;
+  const uint32_t stride = gridDim.x * 4;
+  const uint32_t rounds = (ntiles + stride - 1) / stride;  // every wave runs every round: the barriers are workgroup-wide
+
+  f32x16 acc[NLAYER];  // my dW^T tile of each layer
+#pragma unroll
+  for (int l = 0; l < NLAYER; ++l)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[l][q] = 0.f;
+  float bsum[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) bsum[i] = 0.f;
+  int buf = 0;
+
+  TileIn nxt;
+  {
+    const uint32_t t0 = blockIdx.x * 4 + wv;
+    const uint32_t n0 = t0 * 32 + (lane & 31);
+    load_tile_in<LAYOUT, DT, true>(fs, ps, dout, n0, t0 < ntiles && n0 < fs.N, h, nxt);
+  }
+  for (uint32_t r = 0; r < rounds; ++r) {
+    const uint32_t tile = blockIdx.x * 4 + wv + r * stride;
+    const uint32_t n = tile * 32 + (lane & 31);
+    const bool valid = tile < ntiles && n < fs.N;
+    const TileIn cur = nxt;
+    {
+      const uint32_t tn = tile + stride;
+      const uint32_t nn = tn * 32 + (lane & 31);
+      load_tile_in<LAYOUT, DT, true>(fs, ps, dout, nn, tn < ntiles && nn < fs.N, h, nxt);
+    }
+    Saved<P> sv;
+    forward_tile<P>(img, bias, cur, lane, sv);
+    const int lofs = opaque_lane_offset<P>(lane);
+    const float4 dO = cur.dO;  // zero on invalid lanes => every dZ of such a point is zero
+
+    // ---- C3
+    typename P::frag dz3[P::S8];
+    {
+      f32x16 a;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) a[q] = 0.f;
+      a[0] = dO.x * (sv.raw[0] > 0.f ? 1.f : expf(sv.raw[0]));
+      a[1] = dO.y * (sv.raw[1] > 0.f ? 1.f : expf(sv.raw[1]));
+      a[2] = dO.z * (sv.raw[2] > 0.f ? 1.f : expf(sv.raw[2]));
+#pragma unroll
+      for (int s = 0; s < P::S8; ++s) dz3[s] = P::from_acc(a, s);
+    }
+    exchange_wgrad<P, C3, 2, 1, 2 * P::S32, P::S8>(xch, buf, lane, wv, sv.c2, dz3, acc[C3], bsum + db_base(C3));
+    // ---- C2
+    typename P::frag dzc2[2 * P::S32];
+    {
+      f32x16 a[2];
+      dense<P, 2, P::S8, false>(img, T::b_base(C3), nullptr, lane, lofs, dz3, a);
+      mask_frags<P, 2>(a, sv.c2, dzc2);
+    }
+    exchange_wgrad<P, C2, 2, 2, 2 * P::S32, 2 * P::S32>(xch, buf, lane, wv, sv.c1, dzc2, acc[C2], bsum + db_base(C2));
+    // ---- C1
+    typename P::frag dzc1[2 * P::S32];
+    {
+      f32x16 a[2];
+      dense<P, 2, 2 * P::S32, false>(img, T::b_base(C2), nullptr, lane, lofs, dzc2, a);
+      mask_frags<P, 2>(a, sv.c1, dzc1);
+    }
+    exchange_wgrad<P, C1, 2, 2, P::S32 + P::S8, 2 * P::S32>(xch, buf, lane, wv, sv.cin, dzc1, acc[C1], bsum + db_base(C1));
+    // ---- L3: ds rows 1..15 = d cin slots 1..15 ; row 0 = d sigma * lrelu'(s0)
+    typename P::frag dz_s[P::S16];
+    {
+      f32x16 a[1];
+      dense<P, 1, 2 * P::S32, false>(img, T::b_base(C1), nullptr, lane, lofs, dzc1, a);
+      if (h == 0) a[0][0] = dO.w * (sv.s0 > 0.f ? 1.f : 0.01f);
+#pragma unroll
+      for (int s = 0; s < P::S16; ++s) dz_s[s] = P::from_acc(a[0], s);
+    }
+    exchange_wgrad<P, L3, 2, 1, 2 * P::S32, P::S16>(xch, buf, lane, wv, sv.h2, dz_s, acc[L3], bsum + db_base(L3));
+    // ---- L2
+    typename P::frag dz2[2 * P::S32];
+    {
+      f32x16 a[2];
+      dense<P, 2, P::S16, false>(img, T::b_base(L3), nullptr, lane, lofs, dz_s, a);
+      mask_frags<P, 2>(a, sv.h2, dz2);
+    }
+    exchange_wgrad<P, L2, 2, 2, 2 * P::S32, 2 * P::S32>(xch, buf, lane, wv, sv.h1, dz2, acc[L2], bsum + db_base(L2));
+    // ---- L1
+    typename P::frag dz1[2 * P::S32];
+    {
+      f32x16 a[2];
+      dense<P, 2, 2 * P::S32, false>(img, T::b_base(L2), nullptr, lane, lofs, dz2, a);
+      mask_frags<P, 2>(a, sv.h1, dz1);
+    }
+    exchange_wgrad<P, L1, 1, 2, P::S32, 2 * P::S32>(xch, buf, lane, wv, sv.x0, dz1, acc[L1], bsum + db_base(L1));
+    // ---- d feat
+    if (dfd.p) {
+      f32x16 a[1];
+      dense<P, 1, 2 * P::S32, false>(img, T::b_base(L1), nullptr, lane, lofs, dz1, a);
+      if (valid) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float v0 = a[0][4 * g], v1 = a[0][4 * g + 1], v2 = a[0][4 * g + 2], v3 = a[0][4 * g + 3];
+          const int lvl = 4 * g + 2 * h;
+          if (LAYOUT == HBR_LAYOUT_PLANAR) {
+            if (DT == HBR_F32) {
+              ((float2*)dfd.p)[(size_t)lvl * fs.N + n] = make_float2(v0, v1);
+              ((float2*)dfd.p)[(size_t)(lvl + 1) * fs.N + n] = make_float2(v2, v3);
+            } else {
+              ((uint32_t*)dfd.p)[(size_t)lvl * fs.N + n] = pack_bf16x2(v0, v1);
+              ((uint32_t*)dfd.p)[(size_t)(lvl + 1) * fs.N + n] = pack_bf16x2(v2, v3);
+            }
+          } else {
+            if (DT == HBR_F32) {
+              *(float4*)((float*)dfd.p + (size_t)n * dfd.stride + 2 * lvl) = make_float4(v0, v1, v2, v3);
+            } else {
+              uint2 u = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+              *(uint2*)((uint16_t*)dfd.p + (size_t)n * dfd.stride + 2 * lvl) = u;
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- flush: every wave adds its tiles straight to global memory (once per kernel; <= 6 x 16 x 64 atomics per wave)
+  asm volatile("s_nop 15" ::: "memory");  // last asm MFMA's D -> first VALU reader
+#pragma unroll
+  for (int l = 0; l < NLAYER; ++l) {
+    const int nout = (l == L3 || l == C3) ? 1 : 2;
+    const int tiles = ((l == L1) ? 1 : 2) * nout;
+    const int first = (tiles == 4 || l == C3 || l == L1) ? 0 : 2;
+    const int tau = wv - first;
+    if (tau >= 0 && tau < tiles) {
+      const int nin_t = tau / nout, mout_t = tau % nout;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int i = 32 * nin_t + acc_row(q, h), o = 32 * mout_t + (lane & 31);
+        const int off = wlog_offset(l, o, i);
+        const float v = acc[l][q];
+        if (off >= 0 && v != 0.f) unsafeAtomicAdd(dparams + off, v);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      if (m < nout) {
+        const int off = blog_offset(l, 32 * m + (lane & 31));
+        const float v = bsum[db_base(l) + m];
+        if (off >= 0 && v != 0.f) unsafeAtomicAdd(dparams + off, v);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // view-direction encoding (a7): out[row, c*2nf + k] = sin(2*x_c*k), out[row, c*2nf + nf + k] = cos(2*x_c*k)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dir_encode_kernel(const float* __restrict__ x, int64_t rows, int d, int nf,
@@ -796,11 +1015,28 @@ static void launch_bwd1(uint32_t ntiles, hipStream_t st, const char* img, FeatSr
   hipLaunchKernelGGL(k, dim3(blocks), dim3(NWAVES * 64), lds, st, img, fs, ps, dout, dfd, dparams);
 }
 
+template <class P, int LAYOUT, int DT, bool WLDS>
+static void launch_bwd_fused(uint32_t ntiles, hipStream_t st, const char* img, FeatSrc fs, PeSrc ps, const float* dout,
+                             DFeatDst dfd, float* dparams) {
+  using T = Tab<P>;
+  const int lds = Xch<P>::BYTES + (WLDS ? T::IMG_BYTES : 0);
+  uint32_t blocks = (ntiles + 3) / 4;
+  if (blocks > 256) blocks = 256;  // one workgroup per CU; each sweeps its share of the tiles in rounds of four
+  auto k = mlp_bwd_fused_kernel<P, LAYOUT, DT, WLDS>;
+  hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, st, img, fs, ps, dout, dfd, dparams);
+}
+
 template <int LAYOUT, int DT>
 static void launch_bwd(int precision, uint32_t ntiles, hipStream_t st, const char* img, FeatSrc fs, PeSrc ps, const float* dout,
                        DFeatDst dfd, float* dparams) {
   constexpr int mSig = (1 << L1) | (1 << L2) | (1 << L3), mCol = (1 << C1) | (1 << C2) | (1 << C3);
-#if HBR_BWD_SPLIT == 1
+#if HBR_BWD_SPLIT == 0
+  // single pass, dW tiles shared by the four waves of a workgroup through an LDS fragment exchange
+  if (precision == HBR_BF16) launch_bwd_fused<PBf16, LAYOUT, DT, true>(ntiles, st, img, fs, ps, dout, dfd, dparams);
+  else launch_bwd_fused<PF32, LAYOUT, DT, false>(ntiles, st, img, fs, ps, dout, dfd, dparams);
+  return;
+#elif HBR_BWD_SPLIT == 1
   if (precision == HBR_BF16) {
     launch_bwd1<PBf16, LAYOUT, DT, 4, true, mSig | mCol>(ntiles, st, img, fs, ps, dout, dfd, dparams);
   } else
