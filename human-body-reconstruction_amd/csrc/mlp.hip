@@ -247,10 +247,21 @@ __device__ __forceinline__ void dense(const char* img, int fbase, const float* b
       acc[m][4 * g + 0] = b.x; acc[m][4 * g + 1] = b.y; acc[m][4 * g + 2] = b.z; acc[m][4 * g + 3] = b.w;
     }
   }
+  // The weight fragments of a group of k-steps are all requested before the first MFMA of the group: left to itself
+  // hipcc emits ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma per k-step, exposing the full LDS latency ~100 times per tile.
+  constexpr int G = (P::ELEMS == 8) ? 4 : 8;  // k-steps per group (4 x 4 VGPRs for bf16, 8 x 1 for f32)
 #pragma unroll
   for (int m = 0; m < NOUT; ++m) {
 #pragma unroll
-    for (int ks = 0; ks < NK; ++ks) acc[m] = P::mfma(ldw<P>(img, fbase + m * NK + ks, lofs), x[ks], acc[m]);
+    for (int k0 = 0; k0 < NK; k0 += G) {
+      typename P::frag wf[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        if (k0 + g < NK) wf[g] = ldw<P>(img, fbase + m * NK + k0 + g, lofs);
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        if (k0 + g < NK) acc[m] = P::mfma(wf[g], x[k0 + g], acc[m]);
+    }
   }
 }
 
@@ -753,7 +764,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(const char* __rest
 // layer (<= 6 tiles = 96 accumulator registers): after transposing a layer's X and dZ fragments it parks them in an
 // LDS exchange slot, the workgroup meets at a barrier, and each wave accumulates ITS tile of that layer over the
 // fragments of all four waves (K = 128 points per round).  Layers with four dW tiles give one tile to every wave;
-// layers with two give them to waves {0,1} (C3, L1) or {2,3} (L3).  The exchange buffer is double-buffered, so one
+// layers with two give each tile to a pair of waves that split the four sources.  The exchange buffer is double-buffered, so one
 // barrier per layer suffices: a wave can only overwrite buffer b two layers later, after the next barrier, which
 // every wave reaches only after finishing its reads of b.  No LDS atomics, no second recompute of the forward.
 template <class P>
@@ -782,21 +793,51 @@ __device__ __forceinline__ void exchange_wgrad(char* xch, int& buf, int lane, in
 #pragma unroll
     for (int s = 0; s < P::S32; ++s) *(typename P::frag*)(mine + ((2 + m) * P::S32 + s) * X::FRAG_B) = zt[m][s];
   __syncthreads();
-  // which dW^T tile [in tile n][out tile m] of this layer is mine
+  // Which dW^T tile [in tile n][out tile m] of this layer is mine, and over which source waves.  Four-tile layers:
+  // wave w owns tile w over all four sources.  Two-tile layers: waves {0,1} own tile 0, waves {2,3} tile 1, each over
+  // half of the sources - so every wave runs the same instruction stream (no branch around the accumulator, which
+  // lets it stay in the AGPRs) and the partial tiles simply add up in the final flush.
   constexpr int tiles = NIN * NOUT;
-  const int first = (tiles == 4 || LAYER == C3 || LAYER == L1) ? 0 : 2;
-  const int tau = wv - first;
-  if (tau >= 0 && tau < tiles) {  // wave-uniform
-    const int n = tau / NOUT, m = tau % NOUT;
-    const char* base = xch + buf * X::BUF_B + lane * (int)sizeof(typename P::frag);
+  constexpr int NSRC = (tiles == 4) ? 4 : 2;
+  const int tau = (tiles == 4) ? wv : (wv >> 1);
+  const int src0 = (tiles == 4) ? 0 : 2 * (wv & 1);
+  const int n = tau / NOUT, m = tau % NOUT;
+  const char* base = xch + buf * X::BUF_B + src0 * X::SLOT_B + lane * (int)sizeof(typename P::frag);
+  typename P::frag fa[NSRC][P::S32], fb[NSRC][P::S32];
+  constexpr bool kAllAtOnce = (P::ELEMS == 8);  // bf16: 16 x 4 VGPRs in flight; f32: per source (16 + 16 VGPRs)
+  if (kAllAtOnce) {
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NSRC; ++w)
 #pragma unroll
       for (int s = 0; s < P::S32; ++s) {
-        const typename P::frag a = *(const typename P::frag*)(base + w * X::SLOT_B + (n * P::S32 + s) * X::FRAG_B);
-        const typename P::frag b = *(const typename P::frag*)(base + w * X::SLOT_B + ((2 + m) * P::S32 + s) * X::FRAG_B);
-        P::mfma_acc(a, b, acc);
+        fa[w][s] = *(const typename P::frag*)(base + w * X::SLOT_B + (n * P::S32 + s) * X::FRAG_B);
+        fb[w][s] = *(const typename P::frag*)(base + w * X::SLOT_B + ((2 + m) * P::S32 + s) * X::FRAG_B);
       }
+    // one opaque statement that "uses" every fragment: without it hipcc sinks each ds_read pair back next to its
+    // MFMA and waits lgkmcnt(0) eight times in a row
+    if constexpr (NSRC == 4) {
+      asm volatile("" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]), "+v"(fa[2][1]),
+                        "+v"(fa[3][0]), "+v"(fa[3][1]));
+      asm volatile("" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[2][0]), "+v"(fb[2][1]),
+                        "+v"(fb[3][0]), "+v"(fb[3][1]));
+    } else {
+      asm volatile("" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fb[0][0]), "+v"(fb[0][1]),
+                        "+v"(fb[1][0]), "+v"(fb[1][1]));
+    }
+#pragma unroll
+    for (int w = 0; w < NSRC; ++w)
+#pragma unroll
+      for (int s = 0; s < P::S32; ++s) P::mfma_acc(fa[w][s], fb[w][s], acc);
+  } else {
+#pragma unroll
+    for (int w = 0; w < NSRC; ++w) {
+#pragma unroll
+      for (int s = 0; s < P::S32; ++s) {
+        fa[0][s] = *(const typename P::frag*)(base + w * X::SLOT_B + (n * P::S32 + s) * X::FRAG_B);
+        fb[0][s] = *(const typename P::frag*)(base + w * X::SLOT_B + ((2 + m) * P::S32 + s) * X::FRAG_B);
+      }
+#pragma unroll
+      for (int s = 0; s < P::S32; ++s) P::mfma_acc(fa[0][s], fb[0][s], acc);
     }
   }
   buf ^= 1;
@@ -941,9 +982,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
   for (int l = 0; l < NLAYER; ++l) {
     const int nout = (l == L3 || l == C3) ? 1 : 2;
     const int tiles = ((l == L1) ? 1 : 2) * nout;
-    const int first = (tiles == 4 || l == C3 || l == L1) ? 0 : 2;
-    const int tau = wv - first;
-    if (tau >= 0 && tau < tiles) {
+    const int tau = (tiles == 4) ? wv : (wv >> 1);
+    {
       const int nin_t = tau / nout, mout_t = tau % nout;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
