@@ -1,7 +1,8 @@
 """Scratch timing of the individual kernels at the BASELINE size (not the driver's bench)."""
 import sys, os, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
 import ref_cpu
 from hbr_amd import ops
 from hbr_amd._lib import PLANAR, ROWS, F32, BF16
