@@ -145,14 +145,30 @@ constexpr int kSliceLog2 = 14;                 // 16384 rows * 1 double * 8 B = 
 constexpr int kSliceRows = 1 << kSliceLog2;
 constexpr int kLdsBwdThreads = 1024;
 
+// K2 prologue: the level-independent part of the index computation, (x - mu) / sigma, once per point instead of once
+// per (point, level, slice, feature) visit (three IEEE divisions + the point generation are ~40 % of a visit's VALU
+// work).  Stored in the order the scatter kernel's threads consume it - entry [stripe*1024 + tid] holds point
+// stripe*1024 + perm(tid) - so that its 16-byte reads are fully coalesced.
+__device__ __forceinline__ uint32_t stripe_perm(uint32_t tid) { return (tid & 63u) * 16u + (tid >> 6); }
+
+__global__ __launch_bounds__(1024) void normalise_kernel(PointSrc ps, uint32_t N, HashGeom g, float4* __restrict__ out) {
+  const uint32_t base = blockIdx.x * 1024u;
+  const uint32_t n_raw = base + stripe_perm(threadIdx.x);
+  const uint32_t n = min(n_raw, N - 1);
+  float px, py, pz, nx, ny, nz;
+  load_point(ps, n, px, py, pz);
+  normalise(g, px, py, pz, nx, ny, nz);
+  out[base + threadIdx.x] = make_float4(nx, ny, nz, 0.f);
+}
+
 // One workgroup = (level, 16384-row slice, feature f, chunk of points).  Splitting the two features of a row over
 // two workgroups keeps the slice at 16384 rows with fp64 accumulators, so a point is still visited 8 times per
 // level (4 slices x 2 features) but each visit issues 8 LDS atomics instead of 16.
-template <bool POW2, int LAYOUT, int DTYPE>
+template <bool POW2, int LAYOUT, int DTYPE, bool CACHED>
 __global__ __launch_bounds__(kLdsBwdThreads) void hash_bwd_lds_kernel(PointSrc ps, uint32_t N, const void* __restrict__ dy,
                                                                       int64_t dy_stride, HashGeom g,
                                                                       float* __restrict__ dtables, int slices_per_level,
-                                                                      int chunks) {
+                                                                      int chunks, const float4* __restrict__ xnorm) {
   extern __shared__ double acc[];  // [kSliceRows]
   // block -> (level, slice, feature, chunk); chunk varies fastest so the blocks of one slice start together
   const uint32_t b = blockIdx.x;
@@ -166,7 +182,8 @@ __global__ __launch_bounds__(kLdsBwdThreads) void hash_bwd_lds_kernel(PointSrc p
   __syncthreads();
 
   const uint32_t row_lo = slice << kSliceLog2;
-  const uint32_t per = (N + chunks - 1) / chunks;
+  // chunks are whole 1024-point stripes so that the stripe permutation is the same in every kernel
+  const uint32_t per = ((N + chunks - 1) / chunks + kLdsBwdThreads - 1) / kLdsBwdThreads * kLdsBwdThreads;
   const uint32_t n_begin = chunk * per;
   const uint32_t n_end = min(N, n_begin + per);
   const float scale = g.scale[l];
@@ -179,11 +196,17 @@ __global__ __launch_bounds__(kLdsBwdThreads) void hash_bwd_lds_kernel(PointSrc p
   for (uint32_t base = n_begin; base < n_end; base += kLdsBwdThreads) {
     const uint32_t n = base + perm;
     if (n >= n_end) continue;
-    float px, py, pz, nx, ny, nz, d0, d1;
-    load_point(ps, n, px, py, pz);
+    float nx, ny, nz, d0, d1;
+    if (CACHED) {
+      const float4 q = xnorm[base + threadIdx.x];
+      nx = q.x; ny = q.y; nz = q.z;
+    } else {
+      float px, py, pz;
+      load_point(ps, n, px, py, pz);
+      normalise(g, px, py, pz, nx, ny, nz);
+    }
     load_feat<LAYOUT, DTYPE>(dy, n, l, N, dy_stride, d0, d1);
     const float dv = f ? d1 : d0;
-    normalise(g, px, py, pz, nx, ny, nz);
     Cell c = locate(nx, ny, nz, scale);
     uint32_t rows[8];
     float w[8];
@@ -224,7 +247,7 @@ static int launch_fwd_dtype(int dtype, dim3 grid, hipStream_t st, PointSrc ps, u
 
 template <bool POW2, int LAYOUT, int DTYPE>
 static void launch_bwd(int algo, hipStream_t st, PointSrc ps, uint32_t N, const void* dy, int64_t stride, const HashGeom& g,
-                       float* dtables) {
+                       float* dtables, float4* xnorm) {
   if (algo == 1) {
     const int lpg = (g.L + kXcds - 1) / kXcds;
     const uint32_t tiles = (N + kFwdThreads - 1) / kFwdThreads;
@@ -237,14 +260,17 @@ static void launch_bwd(int algo, hipStream_t st, PointSrc ps, uint32_t N, const 
     int max_chunks = (int)((N + kLdsBwdThreads - 1) / kLdsBwdThreads);
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1) chunks = 1;
-    static bool attr_set[2][2][2] = {};
-    auto kern = hash_bwd_lds_kernel<POW2, LAYOUT, DTYPE>;
-    if (!attr_set[POW2][LAYOUT][DTYPE]) {
-      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kSliceRows * sizeof(double));
-      attr_set[POW2][LAYOUT][DTYPE] = true;
+    const int lds = kSliceRows * (int)sizeof(double);
+    const dim3 grid((uint32_t)(g.L * spl * 2 * chunks));
+    if (xnorm) {
+      auto kern = hash_bwd_lds_kernel<POW2, LAYOUT, DTYPE, true>;
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL(kern, grid, dim3(kLdsBwdThreads), lds, st, ps, N, dy, stride, g, dtables, spl, chunks, (const float4*)xnorm);
+    } else {
+      auto kern = hash_bwd_lds_kernel<POW2, LAYOUT, DTYPE, false>;
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL(kern, grid, dim3(kLdsBwdThreads), lds, st, ps, N, dy, stride, g, dtables, spl, chunks, (const float4*)nullptr);
     }
-    hipLaunchKernelGGL(kern, dim3((uint32_t)(g.L * spl * 2 * chunks)), dim3(kLdsBwdThreads), kSliceRows * sizeof(double), st, ps, N,
-                       dy, stride, g, dtables, spl, chunks);
   }
 }
 
@@ -298,12 +324,16 @@ extern "C" int hbr_hash_encode_fwd(const float* x, const float* rays_o, const fl
   return HBR_OK;
 }
 
-extern "C" int64_t hbr_hash_bwd_workspace_bytes(int64_t, int, int64_t, int, int) { return 0; }
+// optional workspace of the LDS-slice algorithm: normalised coordinates, one float4 per point, padded to whole stripes
+extern "C" int64_t hbr_hash_bwd_workspace_bytes(int64_t N, int, int64_t, int, int algo) {
+  if (algo == 1 || N < 65536) return 0;
+  return (N + 1023) / 1024 * 1024 * (int64_t)sizeof(float4);
+}
 
 extern "C" int hbr_hash_encode_bwd(const float* x, const float* rays_o, const float* rays_d, const float* t, int64_t R,
                                    int64_t S, const void* dy, int layout, int64_t dy_stride, int dy_dtype,
                                    const float* scales_host, const float* mu_host, float sigma, int L, int64_t T, int F,
-                                   float* dtables, int algo, void*, int64_t, void* stream) {
+                                   float* dtables, int algo, void* ws, int64_t ws_bytes, void* stream) {
   if (!dy || !dtables) return HBR_EINVAL;
   if (F != 2) return HBR_EUNSUPPORTED;
   if (layout != HBR_LAYOUT_ROWS && layout != HBR_LAYOUT_PLANAR) return HBR_EINVAL;
@@ -321,7 +351,13 @@ extern "C" int hbr_hash_encode_bwd(const float* x, const float* rays_o, const fl
   // auto: the LDS-slice kernel wins once there are enough points to amortise its fixed 128 KiB flush per block
   if (algo == 0) algo = (N >= 65536u) ? 2 : 1;
   hipStream_t st = (hipStream_t)stream;
-#define HBR_BWD(P, LY, DT) launch_bwd<P, LY, DT>(algo, st, ps, N, dy, dy_stride, g, dtables)
+  float4* xnorm = nullptr;
+  const int64_t stripes = ((int64_t)N + 1023) / 1024;
+  if (algo == 2 && ws && ws_bytes >= stripes * 1024 * (int64_t)sizeof(float4) && (((uintptr_t)ws) & 15) == 0) {
+    xnorm = (float4*)ws;
+    hipLaunchKernelGGL(normalise_kernel, dim3((uint32_t)stripes), dim3(1024), 0, st, ps, N, g, xnorm);
+  }
+#define HBR_BWD(P, LY, DT) launch_bwd<P, LY, DT>(algo, st, ps, N, dy, dy_stride, g, dtables, xnorm)
   if (g.pow2) {
     if (layout == HBR_LAYOUT_PLANAR) { if (dy_dtype == HBR_F32) HBR_BWD(true, HBR_LAYOUT_PLANAR, HBR_F32); else HBR_BWD(true, HBR_LAYOUT_PLANAR, HBR_BF16); }
     else { if (dy_dtype == HBR_F32) HBR_BWD(true, HBR_LAYOUT_ROWS, HBR_F32); else HBR_BWD(true, HBR_LAYOUT_ROWS, HBR_BF16); }

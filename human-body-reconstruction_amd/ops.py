@@ -5,6 +5,7 @@ path runs in libhbr_hip.so.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Optional, Sequence, Tuple
 
@@ -116,8 +117,10 @@ def hash_encode_bwd(geom: HashGeom, dy: torch.Tensor, dtables: torch.Tensor, x: 
     if R * S == 0:
         return dtables
     sc, mu = geom.c_args()
+    nws = 0 if os.environ.get("HBR_K2_NOCACHE") else lib().hbr_hash_bwd_workspace_bytes(R * S, geom.L, geom.T, geom.F, algo)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dy.device) if nws else None
     check(lib().hbr_hash_encode_bwd(_ptr(x), _ptr(o), _ptr(d), _ptr(t), R, S, dy.data_ptr(), layout, stride, dtype, sc, mu,
-                                    geom.sigma, geom.L, geom.T, geom.F, dtables.data_ptr(), algo, None, 0, _stream()),
+                                    geom.sigma, geom.L, geom.T, geom.F, dtables.data_ptr(), algo, _ptr(ws), nws, _stream()),
           "hbr_hash_encode_bwd")
     return dtables
 

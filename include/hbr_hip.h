@@ -72,7 +72,8 @@ int hbr_hash_encode_fwd(const float* x, const float* rays_o, const float* rays_d
  *   dy       same layout/dtype conventions as y
  *   dtables  [L,T,F] fp32, ACCUMULATED INTO (caller zeroes it when a fresh gradient is wanted)
  *   algo     0 = auto, 1 = global float atomics, 2 = LDS-partitioned accumulate + slab flush
- *   ws       workspace (hbr_hash_bwd_workspace_bytes), may be NULL when that returns 0
+ *   ws       optional 16-byte-aligned scratch of hbr_hash_bwd_workspace_bytes() bytes (the LDS-slice algorithm
+ *            caches the normalised coordinates there once per call); NULL / too small => recomputed per visit
  */
 int hbr_hash_encode_bwd(const float* x, const float* rays_o, const float* rays_d, const float* t,
                         int64_t R, int64_t S, const void* dy, int layout, int64_t dy_stride,
