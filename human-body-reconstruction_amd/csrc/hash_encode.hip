@@ -151,14 +151,15 @@ constexpr int kLdsBwdThreads = 1024;
 // stripe*1024 + perm(tid) - so that its 16-byte reads are fully coalesced.
 __device__ __forceinline__ uint32_t stripe_perm(uint32_t tid) { return (tid & 63u) * 16u + (tid >> 6); }
 
-__global__ __launch_bounds__(1024) void normalise_kernel(PointSrc ps, uint32_t N, HashGeom g, float4* __restrict__ out) {
+__global__ __launch_bounds__(1024) void normalise_kernel(PointSrc ps, uint32_t N, HashGeom g, float* __restrict__ out) {
   const uint32_t base = blockIdx.x * 1024u;
   const uint32_t n_raw = base + stripe_perm(threadIdx.x);
   const uint32_t n = min(n_raw, N - 1);
   float px, py, pz, nx, ny, nz;
   load_point(ps, n, px, py, pz);
   normalise(g, px, py, pz, nx, ny, nz);
-  out[base + threadIdx.x] = make_float4(nx, ny, nz, 0.f);
+  float* q = out + (size_t)(base + threadIdx.x) * 3;  // 12 B per entry: K2 re-reads this buffer 128x per call
+  q[0] = nx; q[1] = ny; q[2] = nz;
 }
 
 // One workgroup = (level, 16384-row slice, feature f, chunk of points).  Splitting the two features of a row over
@@ -168,7 +169,7 @@ template <bool POW2, int LAYOUT, int DTYPE, bool CACHED>
 __global__ __launch_bounds__(kLdsBwdThreads) void hash_bwd_lds_kernel(PointSrc ps, uint32_t N, const void* __restrict__ dy,
                                                                       int64_t dy_stride, HashGeom g,
                                                                       float* __restrict__ dtables, int slices_per_level,
-                                                                      int chunks, const float4* __restrict__ xnorm) {
+                                                                      int chunks, const float* __restrict__ xnorm) {
   extern __shared__ double acc[];  // [kSliceRows]
   // block -> (level, slice, feature, chunk); chunk varies fastest so the blocks of one slice start together
   const uint32_t b = blockIdx.x;
@@ -198,8 +199,8 @@ __global__ __launch_bounds__(kLdsBwdThreads) void hash_bwd_lds_kernel(PointSrc p
     if (n >= n_end) continue;
     float nx, ny, nz, d0, d1;
     if (CACHED) {
-      const float4 q = xnorm[base + threadIdx.x];
-      nx = q.x; ny = q.y; nz = q.z;
+      const float* q = xnorm + (size_t)(base + threadIdx.x) * 3;
+      nx = q[0]; ny = q[1]; nz = q[2];
     } else {
       float px, py, pz;
       load_point(ps, n, px, py, pz);
@@ -247,7 +248,7 @@ static int launch_fwd_dtype(int dtype, dim3 grid, hipStream_t st, PointSrc ps, u
 
 template <bool POW2, int LAYOUT, int DTYPE>
 static void launch_bwd(int algo, hipStream_t st, PointSrc ps, uint32_t N, const void* dy, int64_t stride, const HashGeom& g,
-                       float* dtables, float4* xnorm) {
+                       float* dtables, float* xnorm) {
   if (algo == 1) {
     const int lpg = (g.L + kXcds - 1) / kXcds;
     const uint32_t tiles = (N + kFwdThreads - 1) / kFwdThreads;
@@ -265,11 +266,11 @@ static void launch_bwd(int algo, hipStream_t st, PointSrc ps, uint32_t N, const 
     if (xnorm) {
       auto kern = hash_bwd_lds_kernel<POW2, LAYOUT, DTYPE, true>;
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      hipLaunchKernelGGL(kern, grid, dim3(kLdsBwdThreads), lds, st, ps, N, dy, stride, g, dtables, spl, chunks, (const float4*)xnorm);
+      hipLaunchKernelGGL(kern, grid, dim3(kLdsBwdThreads), lds, st, ps, N, dy, stride, g, dtables, spl, chunks, (const float*)xnorm);
     } else {
       auto kern = hash_bwd_lds_kernel<POW2, LAYOUT, DTYPE, false>;
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      hipLaunchKernelGGL(kern, grid, dim3(kLdsBwdThreads), lds, st, ps, N, dy, stride, g, dtables, spl, chunks, (const float4*)nullptr);
+      hipLaunchKernelGGL(kern, grid, dim3(kLdsBwdThreads), lds, st, ps, N, dy, stride, g, dtables, spl, chunks, (const float*)nullptr);
     }
   }
 }
@@ -324,10 +325,10 @@ extern "C" int hbr_hash_encode_fwd(const float* x, const float* rays_o, const fl
   return HBR_OK;
 }
 
-// optional workspace of the LDS-slice algorithm: normalised coordinates, one float4 per point, padded to whole stripes
+// optional workspace of the LDS-slice algorithm: normalised coordinates, 3 floats per point, padded to whole stripes
 extern "C" int64_t hbr_hash_bwd_workspace_bytes(int64_t N, int, int64_t, int, int algo) {
   if (algo == 1 || N < 65536) return 0;
-  return (N + 1023) / 1024 * 1024 * (int64_t)sizeof(float4);
+  return (N + 1023) / 1024 * 1024 * 3 * (int64_t)sizeof(float);
 }
 
 extern "C" int hbr_hash_encode_bwd(const float* x, const float* rays_o, const float* rays_d, const float* t, int64_t R,
@@ -351,10 +352,10 @@ extern "C" int hbr_hash_encode_bwd(const float* x, const float* rays_o, const fl
   // auto: the LDS-slice kernel wins once there are enough points to amortise its fixed 128 KiB flush per block
   if (algo == 0) algo = (N >= 65536u) ? 2 : 1;
   hipStream_t st = (hipStream_t)stream;
-  float4* xnorm = nullptr;
+  float* xnorm = nullptr;
   const int64_t stripes = ((int64_t)N + 1023) / 1024;
-  if (algo == 2 && ws && ws_bytes >= stripes * 1024 * (int64_t)sizeof(float4) && (((uintptr_t)ws) & 15) == 0) {
-    xnorm = (float4*)ws;
+  if (algo == 2 && ws && ws_bytes >= stripes * 1024 * 3 * (int64_t)sizeof(float) && (((uintptr_t)ws) & 15) == 0) {
+    xnorm = (float*)ws;
     hipLaunchKernelGGL(normalise_kernel, dim3((uint32_t)stripes), dim3(1024), 0, st, ps, N, g, xnorm);
   }
 #define HBR_BWD(P, LY, DT) launch_bwd<P, LY, DT>(algo, st, ps, N, dy, dy_stride, g, dtables, xnorm)
