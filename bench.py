@@ -78,8 +78,10 @@ def main():
     pool = 8
     batches = []
     for b in range(pool):
-        o, d, dn, gt = ref_cpu.synthetic_rays(R, seed=1000 + rank * pool + b)
-        batches.append(tuple(a.to(dev).contiguous() for a in (o, d, dn.reshape(-1), gt)))
+        # rays toward the object from the upper hemisphere; ground truth = the analytic solid of ref_cpu.analytic_field
+        # composited on a fine quadrature (a consistent radiance field, so the loss/PSNR of the run mean something)
+        o, d, dn, gt = ref_cpu.synthetic_scene_rays(R, seed=1000 + rank * pool + b, device=dev)
+        batches.append(tuple(a.contiguous() for a in (o, d, dn.reshape(-1), gt)))
     enc, denc, mlp = build_default_model(mn, sig, dev, seed=0)  # same init on every rank (replicated parameters)
     prec = _lib.BF16 if args.precision == "bf16" else _lib.F32
     fdt = _lib.BF16 if args.feat_dtype == "bf16" else _lib.F32

@@ -377,3 +377,35 @@ def render_hierarchical(o, d, t, dir_norm, tables, scales, mu, sigma, mlp_params
     out_f = mlp_forward(feat_f, pe_f, mlp_params)
     Cf, _ = composite_per_ray(t_f, out_f[:, 0:3].reshape(R, S2, 3), out_f[:, 3].reshape(R, S2), dir_norm)
     return Cr, Cf
+
+
+# --------------------------------------------------------------------------------------
+# multi-view-consistent synthetic scene (analytic density/colour field inside |x| < 1.2)
+# --------------------------------------------------------------------------------------
+def analytic_field(x: torch.Tensor):
+    """A smooth 'lego-like' solid: union of three soft boxes and a sphere.  Returns (sigma >= 0 [..], rgb [..,3])."""
+    def box(c, h):
+        q = (x - torch.tensor(c, dtype=x.dtype, device=x.device)).abs() - torch.tensor(h, dtype=x.dtype, device=x.device)
+        return q.max(dim=-1).values  # signed distance-like (negative inside)
+    d = torch.minimum(torch.minimum(box((0.0, 0.0, -0.3), (0.9, 0.6, 0.2)), box((-0.3, 0.0, 0.1), (0.4, 0.35, 0.25))),
+                      box((0.45, 0.1, 0.15), (0.2, 0.45, 0.3)))
+    d = torch.minimum(d, (x - torch.tensor((0.0, -0.2, 0.55), dtype=x.dtype, device=x.device)).norm(dim=-1) - 0.3)
+    sigma = 25.0 * torch.sigmoid(-d / 0.03)
+    rgb = 0.5 + 0.5 * torch.sin(4.0 * x + torch.tensor((0.0, 2.0, 4.0), dtype=x.dtype, device=x.device))
+    return sigma, rgb
+
+
+def synthetic_scene_rays(R: int, seed: int = 0, radius: float = 4.03, near: float = 2.0, far: float = 6.0, quad: int = 384,
+                         device="cpu"):
+    """Rays as synthetic_rays(), but with ground truth rendered from analytic_field by the reference's own compositing
+    rule on a fine uniform quadrature (so the target is a consistent radiance field and PSNR means something).
+    dir_norm = 1.  Returns o, d, dir_norm[R,1], gt[R,3] on `device`."""
+    o, d, _, _ = synthetic_rays(R, seed=seed, radius=radius)
+    o, d = o.to(device), d.to(device)
+    t = torch.linspace(near, far, quad, device=device)
+    gts = []
+    for i in range(0, R, 4096):
+        pts = sample_points(o[i:i + 4096], d[i:i + 4096], t)
+        sg, rgb = analytic_field(pts)
+        gts.append(composite(t, rgb, sg, 1)[0])
+    return o, d, torch.ones((R, 1), device=device), torch.cat(gts).clamp(0, 1)

@@ -1,0 +1,45 @@
+"""PSNR after a short training run: CPU oracle (fp32 and under torch's bf16 autocast) vs the HIP trainer (fp32 / bf16)."""
+import sys, os, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+import numpy as np, torch, ref_cpu
+from hbr_amd._lib import BF16, F32
+from hbr_amd.helper import calc_psnr
+from hbr_amd.trainer import HashNeRFTrainer, build_default_model
+dev = "cuda:0"
+torch.set_num_threads(16)
+R, S, L, T, steps = 1024, 48, 16, 2 ** 12, int(os.environ.get("STEPS", "200"))
+o0, d0, _, _ = ref_cpu.synthetic_rays(8192, seed=0)
+mn, mx, sig = ref_cpu.bbox_mu_sigma(o0, d0)
+rng = np.random.default_rng(7)
+tables0 = torch.from_numpy(rng.uniform(-1e-4, 1e-4, (L, T, 2)).astype(np.float32))
+params0 = ref_cpu.mlp_init(8)
+batches = [ref_cpu.synthetic_scene_rays(R, seed=50 + i) for i in range(16)]
+test = ref_cpu.synthetic_scene_rays(2048, seed=999)
+ts = [ref_cpu.strat_jitter_to_t(2.0, 6.0, S, torch.from_numpy(rng.uniform(0, 1, S).astype(np.float32))) for _ in range(steps)]
+t_eval = torch.linspace(2.0, 6.0, S)
+sc = ref_cpu.level_scales(16, 2048.0, L)
+res = {}
+for name, ac in (() if os.environ.get("SKIP_ORACLE") else (("oracle fp32", False), ("oracle bf16-autocast", True))):
+    tabs = [tables0[l].clone().requires_grad_(True) for l in range(L)]
+    prm = {k: v.clone().requires_grad_(True) for k, v in params0.items()}
+    opts = ref_cpu.make_optimizers(tabs, prm.values(), steps)
+    t0 = time.time()
+    for k in range(steps):
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=ac):
+            ref_cpu.train_step(batches[k % 16], ts[k], tabs, sc, mn, sig, prm, opts)
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16, enabled=ac):
+        C, _, _ = ref_cpu.render(test[0], test[1], t_eval, test[2], tabs, sc, mn, sig, prm)
+    res[name] = float(ref_cpu.psnr(C.float(), test[3]))
+    print(f"{name:24s} PSNR {res[name]:.2f} dB  ({time.time()-t0:.0f}s)", flush=True)
+for name, prec in (("HIP fp32 run 1", F32), ("HIP fp32 run 2", F32), ("HIP fp32 run 3", F32), ("HIP bf16 run 1", BF16), ("HIP bf16 run 2", BF16)):
+    enc, denc, mlp = build_default_model(mn, sig, dev, L=L, T=T, seed=0)
+    with torch.no_grad():
+        for l in range(L): enc.Embedding_list[l].weight.copy_(tables0[l])
+        for k, v in params0.items():
+            seq, idx, kind = k.split("."); getattr(getattr(mlp, seq)[int(idx)], kind).copy_(v)
+    tr = HashNeRFTrainer(enc, mlp, num_samples=S, total_steps=steps, precision=prec)
+    for k in range(steps):
+        tr.step(*(a.to(dev) for a in batches[k % 16]), t=ts[k].to(dev))
+    C = tr.render(test[0].to(dev), test[1].to(dev), test[2].to(dev), t=t_eval.to(dev))
+    res[name] = float(calc_psnr(C.cpu(), test[3]))
+    print(f"{name:24s} PSNR {res[name]:.2f} dB", flush=True)
