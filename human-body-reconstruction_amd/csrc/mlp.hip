@@ -1070,34 +1070,27 @@ static void launch_bwd_fused(uint32_t ntiles, hipStream_t st, const char* img, F
 template <int LAYOUT, int DT>
 static void launch_bwd(int precision, uint32_t ntiles, hipStream_t st, const char* img, FeatSrc fs, PeSrc ps, const float* dout,
                        DFeatDst dfd, float* dparams) {
-  constexpr int mSig = (1 << L1) | (1 << L2) | (1 << L3), mCol = (1 << C1) | (1 << C2) | (1 << C3);
 #if HBR_BWD_SPLIT == 0
   // single pass, dW tiles shared by the four waves of a workgroup through an LDS fragment exchange
   if (precision == HBR_BF16) launch_bwd_fused<PBf16, LAYOUT, DT, true>(ntiles, st, img, fs, ps, dout, dfd, dparams);
   else launch_bwd_fused<PF32, LAYOUT, DT, false>(ntiles, st, img, fs, ps, dout, dfd, dparams);
-  return;
-#elif HBR_BWD_SPLIT == 1
+#else
+  // earlier design kept for A/B builds (-DHBR_BWD_SPLIT=2|3): per-wave dW tiles, several launches by layer mask
+  constexpr int mSig = (1 << L1) | (1 << L2) | (1 << L3), mCol = (1 << C1) | (1 << C2) | (1 << C3);
   if (precision == HBR_BF16) {
-    launch_bwd1<PBf16, LAYOUT, DT, 4, true, mSig | mCol>(ntiles, st, img, fs, ps, dout, dfd, dparams);
-  } else
-#elif HBR_BWD_SPLIT == 3
-  // three launches, two waves per SIMD (<= 256 registers): {C3,C2}, {C1,L3}, {L2,L1 + d feat}
-  if (precision == HBR_BF16) {
+#if HBR_BWD_SPLIT == 3
     launch_bwd1<PBf16, LAYOUT, DT, 8, true, (1 << C3) | (1 << C2)>(ntiles, st, img, fs, ps, dout, dfd, dparams);
     launch_bwd1<PBf16, LAYOUT, DT, 8, true, (1 << C1) | (1 << L3)>(ntiles, st, img, fs, ps, dout, dfd, dparams);
     launch_bwd1<PBf16, LAYOUT, DT, 8, true, (1 << L2) | (1 << L1)>(ntiles, st, img, fs, ps, dout, dfd, dparams);
-  } else
 #else
-  // two launches, one wave per SIMD (4 waves per workgroup, up to 512 registers): density net + d feat, colour net
-  if (precision == HBR_BF16) {
     launch_bwd1<PBf16, LAYOUT, DT, 4, true, mSig>(ntiles, st, img, fs, ps, dout, dfd, dparams);
     launch_bwd1<PBf16, LAYOUT, DT, 4, true, mCol>(ntiles, st, img, fs, ps, dout, dfd, dparams);
-  } else
 #endif
-  {
+  } else {
     launch_bwd1<PF32, LAYOUT, DT, 4, false, mSig>(ntiles, st, img, fs, ps, dout, dfd, dparams);
     launch_bwd1<PF32, LAYOUT, DT, 4, false, mCol>(ntiles, st, img, fs, ps, dout, dfd, dparams);
   }
+#endif
 }
 
 static int check_common(const void* feat, int layout, int64_t stride, int dt, const float* pe, int64_t N, int64_t group,
