@@ -24,6 +24,7 @@ namespace mlp {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // flat parameter block (hbr_hip.h): offsets of the six nn.Linear layers
 constexpr int OFF_S0W = 0, OFF_S0B = 2048, OFF_S2W = 2112, OFF_S2B = 6208, OFF_S4W = 6272, OFF_S4B = 7296;
@@ -289,7 +290,6 @@ __device__ __forceinline__ void mask_frags(f32x16 (&acc)[NT], const typename P::
       if constexpr (P::ELEMS == 8) {
         // a ReLU output is positive exactly where its bf16 bits are non-zero; test the packed pairs directly
         // (a per-element __builtin_bit_cast<uint16_t>(h[..][j]) test gave wrong masks with hipcc 7.2 - keep the u32 form)
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         const u32x4 hw = __builtin_bit_cast(u32x4, h[t * P::S32 + s]);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -761,12 +761,17 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(const char* __rest
 // ------------------------------------------------------------------------------------------------
 // mlp_bwd_kernel above needs two launches because one wave cannot hold all 18 dW tiles (288 registers) next to its
 // working set.  Here every wave still runs the whole chain for its own 32-point tile, but owns only ONE dW tile per
-// layer (<= 6 tiles = 96 accumulator registers): after transposing a layer's X and dZ fragments it parks them in an
-// LDS exchange slot, the workgroup meets at a barrier, and each wave accumulates ITS tile of that layer over the
-// fragments of all four waves (K = 128 points per round).  Layers with four dW tiles give one tile to every wave;
+// layer (<= 6 tiles = 96 accumulator registers): it parks a layer's X and dZ fragments in an LDS exchange slot
+// (xch_put), runs the next layer's dense while the others catch up, then the workgroup meets at a barrier and each
+// wave accumulates ITS tile of that layer over the fragments of all four waves (xch_take; K = 128 points per round).
+// bf16: the slot is a [point][feature] image written straight from the orientation-1 fragments and read back with
+// the transposing LDS read; f32: the fragments are transposed with identity MFMAs first (no 32-bit transposing read).  Layers with four dW tiles give one tile to every wave;
 // layers with two give each tile to a pair of waves that split the four sources.  The exchange buffer is double-buffered, so one
 // barrier per layer suffices: a wave can only overwrite buffer b two layers later, after the next barrier, which
 // every wave reaches only after finishing its reads of b.  No LDS atomics, no second recompute of the forward.
+#ifndef HBR_XCH_TR
+#define HBR_XCH_TR 1  // bf16: exchange through a [point][feature] image + ds_read_b64_tr_b16 (0: identity-MFMA transposes)
+#endif
 template <class P>
 struct Xch {
   static constexpr int FRAG_B = (int)sizeof(typename P::frag) * 64;
@@ -776,68 +781,181 @@ struct Xch {
   static constexpr int BYTES = 2 * BUF_B;
 };
 
-template <class P, int LAYER, int NIN, int NOUT, int NKX, int NKZ>
-__device__ __forceinline__ void exchange_wgrad(char* xch, int& buf, int lane, int wv, const typename P::frag (&x)[NKX],
-                                               const typename P::frag (&dz)[NKZ], f32x16& acc, float* colsum) {
+// bf16 exchange image: a wave's slot is [32 points][128 features x 2 B] (X in chunks 0..7, dZ in chunks 8..15 of a
+// 256-B row), written straight from the orientation-1 fragments and read back by the dW owners with the transposing
+// LDS read (ds_read_b64_tr_b16), which yields the k = point fragments the wgrad MFMA needs - no identity-MFMA
+// transposes.  16-B chunks are XOR-swizzled by the row (cdna_hip_programming.md T10, image (b)): transposed reads are
+// conflict-free, the 8-B writes 2-way.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int xch_off(int row, int chunk) {
+  return 256 * row + 16 * (chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+__device__ __forceinline__ bf16x8 lds_tr_frag(const char* lo, const char* hi) {
+  const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)lo);
+  const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)hi);
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ float frag_sum(bf16x8 f, float acc) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 one;
+  one[0] = (__bf16)1.f; one[1] = (__bf16)1.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    bf16x2 p;
+    p[0] = f[2 * i]; p[1] = f[2 * i + 1];
+    acc = __builtin_amdgcn_fdot2_f32_bf16(p, one, acc, false);
+  }
+  return acc;
+}
+
+// Which dW^T tile [in tile n][out tile m] of a layer a wave owns, and over which source waves.  Four-tile layers:
+// wave w owns tile w over all four sources.  Two-tile layers: waves {0,1} own tile 0, waves {2,3} tile 1, each over
+// half of the sources - so every wave runs the same instruction stream (no branch around the accumulator, which
+// lets it stay in the AGPRs) and the partial tiles simply add up in the final flush.
+template <int NIN, int NOUT>
+struct Own {
+  static constexpr int tiles = NIN * NOUT;
+  static constexpr int NSRC = (tiles == 4) ? 4 : 2;
+  int n, m, src0;
+  __device__ __forceinline__ explicit Own(int wv) {
+    const int tau = (tiles == 4) ? wv : (wv >> 1);
+    src0 = (tiles == 4) ? 0 : 2 * (wv & 1);
+    n = tau / NOUT;
+    m = tau % NOUT;
+  }
+};
+
+// ---- first half of a layer's exchange: park this wave's X and dZ fragments in its slot of buffer `buf`
+template <class P, int NIN, int NOUT, int NKX, int NKZ>
+__device__ __forceinline__ void xch_put(char* xch, int buf, int lane, int wv, const typename P::frag (&x)[NKX],
+                                        const typename P::frag (&dz)[NKZ], float* colsum) {
   using X = Xch<P>;
-  typename P::frag xt[NIN][P::S32], zt[NOUT][P::S32];
-  transpose_frags<P, NIN, NKX, false>(x, lane, xt);
-  transpose_frags<P, NOUT, NKZ, true>(dz, lane, zt, colsum);
-  char* mine = xch + buf * X::BUF_B + wv * X::SLOT_B + lane * (int)sizeof(typename P::frag);
+  if constexpr (P::ELEMS == 8 && HBR_XCH_TR) {
+    static_assert(X::SLOT_B == 32 * 256, "slot = 32 point rows of 256 B");
+    const int pt = lane & 31, h = lane >> 5;
+    char* mine = xch + buf * X::BUF_B + wv * X::SLOT_B + 256 * pt + 8 * h;
+    const int sw16 = 16 * (((pt & 3) << 2) | ((pt >> 2) & 3));
 #pragma unroll
-  for (int n = 0; n < NIN; ++n)
-#pragma unroll
-    for (int s = 0; s < P::S32; ++s) *(typename P::frag*)(mine + (n * P::S32 + s) * X::FRAG_B) = xt[n][s];
-#pragma unroll
-  for (int m = 0; m < NOUT; ++m)
-#pragma unroll
-    for (int s = 0; s < P::S32; ++s) *(typename P::frag*)(mine + ((2 + m) * P::S32 + s) * X::FRAG_B) = zt[m][s];
-  __syncthreads();
-  // Which dW^T tile [in tile n][out tile m] of this layer is mine, and over which source waves.  Four-tile layers:
-  // wave w owns tile w over all four sources.  Two-tile layers: waves {0,1} own tile 0, waves {2,3} tile 1, each over
-  // half of the sources - so every wave runs the same instruction stream (no branch around the accumulator, which
-  // lets it stay in the AGPRs) and the partial tiles simply add up in the final flush.
-  constexpr int tiles = NIN * NOUT;
-  constexpr int NSRC = (tiles == 4) ? 4 : 2;
-  const int tau = (tiles == 4) ? wv : (wv >> 1);
-  const int src0 = (tiles == 4) ? 0 : 2 * (wv & 1);
-  const int n = tau / NOUT, m = tau % NOUT;
-  const char* base = xch + buf * X::BUF_B + src0 * X::SLOT_B + lane * (int)sizeof(typename P::frag);
-  typename P::frag fa[NSRC][P::S32], fb[NSRC][P::S32];
-  constexpr bool kAllAtOnce = (P::ELEMS == 8);  // bf16: 16 x 4 VGPRs in flight; f32: per source (16 + 16 VGPRs)
-  if (kAllAtOnce) {
-#pragma unroll
-    for (int w = 0; w < NSRC; ++w)
-#pragma unroll
-      for (int s = 0; s < P::S32; ++s) {
-        fa[w][s] = *(const typename P::frag*)(base + w * X::SLOT_B + (n * P::S32 + s) * X::FRAG_B);
-        fb[w][s] = *(const typename P::frag*)(base + w * X::SLOT_B + ((2 + m) * P::S32 + s) * X::FRAG_B);
-      }
-    // one opaque statement that "uses" every fragment: without it hipcc sinks each ds_read pair back next to its
-    // MFMA and waits lgkmcnt(0) eight times in a row
-    if constexpr (NSRC == 4) {
-      asm volatile("" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]), "+v"(fa[2][1]),
-                        "+v"(fa[3][0]), "+v"(fa[3][1]));
-      asm volatile("" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[2][0]), "+v"(fb[2][1]),
-                        "+v"(fb[3][0]), "+v"(fb[3][1]));
-    } else {
-      asm volatile("" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fb[0][0]), "+v"(fb[0][1]),
-                        "+v"(fb[1][0]), "+v"(fb[1][1]));
+    for (int ks = 0; ks < NKX; ++ks) {  // fragment (tile ks/2, step ks%2): elements 0..3 -> features 32n+16s+4h.., 4..7 -> +8
+      const u32x4 w = __builtin_bit_cast(u32x4, x[ks]);
+      const int ch = 4 * (ks / 2) + 2 * (ks % 2);
+      *(uint2*)(mine + ((16 * ch) ^ sw16)) = make_uint2(w[0], w[1]);
+      *(uint2*)(mine + ((16 * (ch + 1)) ^ sw16)) = make_uint2(w[2], w[3]);
     }
 #pragma unroll
+    for (int ks = 0; ks < NKZ; ++ks) {
+      const u32x4 w = __builtin_bit_cast(u32x4, dz[ks]);
+      const int ch = 8 + 4 * (ks / 2) + 2 * (ks % 2);
+      *(uint2*)(mine + ((16 * ch) ^ sw16)) = make_uint2(w[0], w[1]);
+      *(uint2*)(mine + ((16 * (ch + 1)) ^ sw16)) = make_uint2(w[2], w[3]);
+    }
+  } else {
+    typename P::frag xt[NIN][P::S32], zt[NOUT][P::S32];
+    transpose_frags<P, NIN, NKX, false>(x, lane, xt);
+    transpose_frags<P, NOUT, NKZ, true>(dz, lane, zt, colsum);
+    char* mine = xch + buf * X::BUF_B + wv * X::SLOT_B + lane * (int)sizeof(typename P::frag);
+#pragma unroll
+    for (int n = 0; n < NIN; ++n)
+#pragma unroll
+      for (int s = 0; s < P::S32; ++s) *(typename P::frag*)(mine + (n * P::S32 + s) * X::FRAG_B) = xt[n][s];
+#pragma unroll
+    for (int m = 0; m < NOUT; ++m)
+#pragma unroll
+      for (int s = 0; s < P::S32; ++s) *(typename P::frag*)(mine + ((2 + m) * P::S32 + s) * X::FRAG_B) = zt[m][s];
+  }
+}
+
+// ---- second half: meet the workgroup, then accumulate MY dW^T tile of the layer over the source waves' fragments
+template <class P, int NIN, int NOUT>
+__device__ __forceinline__ void xch_take(char* xch, int& buf, int lane, int wv, f32x16& acc, float* colsum) {
+  using X = Xch<P>;
+  using O = Own<NIN, NOUT>;
+  constexpr int NSRC = O::NSRC;
+  __syncthreads();
+  const O own(wv);
+  if constexpr (P::ELEMS == 8 && HBR_XCH_TR) {
+    // lane (group g of its half, q, p) supplies row q, columns 4p..4p+3 of its group's 4-point x 16-feature block
+    const int h = lane >> 5, g = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+    const char* src = xch + buf * X::BUF_B + own.src0 * X::SLOT_B + 8 * (p & 1);
+    const char* a0 = src + xch_off(8 * h + q, 4 * own.n + 2 * g + (p >> 1));
+    const char* a1 = src + xch_off(8 * h + 4 + q, 4 * own.n + 2 * g + (p >> 1));
+    const char* b0 = src + xch_off(8 * h + q, 8 + 4 * own.m + 2 * g + (p >> 1));
+    const char* b1 = src + xch_off(8 * h + 4 + q, 8 + 4 * own.m + 2 * g + (p >> 1));
+    bf16x8 fa[NSRC][2], fb[NSRC][2];
+#pragma unroll
     for (int w = 0; w < NSRC; ++w)
 #pragma unroll
-      for (int s = 0; s < P::S32; ++s) P::mfma_acc(fa[w][s], fb[w][s], acc);
-  } else {
+      for (int s = 0; s < 2; ++s) {  // points 16s + 8h + j of source wave src0 + w
+        const int o = w * X::SLOT_B + s * 16 * 256;
+        fa[w][s] = lds_tr_frag(a0 + o, a1 + o);
+        fb[w][s] = lds_tr_frag(b0 + o, b1 + o);
+      }
+    // all reads are issued before the first MFMA; each source's fragments are then claimed in turn, so the waits are
+    // lgkmcnt(remaining) rather than eight full drains (hipcc otherwise sinks every read next to its MFMA)
 #pragma unroll
     for (int w = 0; w < NSRC; ++w) {
+      asm volatile("" : "+v"(fa[w][0]), "+v"(fa[w][1]), "+v"(fb[w][0]), "+v"(fb[w][1]));
 #pragma unroll
-      for (int s = 0; s < P::S32; ++s) {
-        fa[0][s] = *(const typename P::frag*)(base + w * X::SLOT_B + (n * P::S32 + s) * X::FRAG_B);
-        fb[0][s] = *(const typename P::frag*)(base + w * X::SLOT_B + ((2 + m) * P::S32 + s) * X::FRAG_B);
+      for (int s = 0; s < 2; ++s) PBf16::mfma_acc(fa[w][s], fb[w][s], acc);
+    }
+    // bias gradient of out tile m = sum over points of dZ.  Every (out tile, source) pair is summed by exactly one of
+    // the waves that read it: the owners of (n, m) for n = 0, 1 split a four-source list by n.
+    float bs = 0.f;
+    if constexpr (O::tiles == 4) {
+      if (own.n == 0) {
+        bs = frag_sum(fb[0][0], bs); bs = frag_sum(fb[0][1], bs); bs = frag_sum(fb[1][0], bs); bs = frag_sum(fb[1][1], bs);
+      } else {
+        bs = frag_sum(fb[2][0], bs); bs = frag_sum(fb[2][1], bs); bs = frag_sum(fb[3][0], bs); bs = frag_sum(fb[3][1], bs);
+      }
+    } else if constexpr (NIN == 2) {  // NOUT == 1: the n = 0 and n = 1 owners read the same two sources
+      if (own.n == 0) {
+        bs = frag_sum(fb[0][0], bs); bs = frag_sum(fb[0][1], bs);
+      } else {
+        bs = frag_sum(fb[1][0], bs); bs = frag_sum(fb[1][1], bs);
+      }
+    } else {  // NIN == 1: one owner per (m, source pair)
+      bs = frag_sum(fb[0][0], bs); bs = frag_sum(fb[0][1], bs); bs = frag_sum(fb[1][0], bs); bs = frag_sum(fb[1][1], bs);
+    }
+    colsum[0] += (own.m == 0) ? bs : 0.f;
+    if constexpr (NOUT == 2) colsum[1] += (own.m == 1) ? bs : 0.f;
+  } else {
+    const char* base = xch + buf * X::BUF_B + own.src0 * X::SLOT_B + lane * (int)sizeof(typename P::frag);
+    typename P::frag fa[NSRC][P::S32], fb[NSRC][P::S32];
+    constexpr bool kAllAtOnce = (P::ELEMS == 8);  // bf16: 16 x 4 VGPRs in flight; f32: per source (16 + 16 VGPRs)
+    if (kAllAtOnce) {
+#pragma unroll
+      for (int w = 0; w < NSRC; ++w)
+#pragma unroll
+        for (int s = 0; s < P::S32; ++s) {
+          fa[w][s] = *(const typename P::frag*)(base + w * X::SLOT_B + (own.n * P::S32 + s) * X::FRAG_B);
+          fb[w][s] = *(const typename P::frag*)(base + w * X::SLOT_B + ((2 + own.m) * P::S32 + s) * X::FRAG_B);
+        }
+      // one opaque statement that "uses" every fragment: without it hipcc sinks each ds_read pair back next to its
+      // MFMA and waits lgkmcnt(0) eight times in a row
+      if constexpr (NSRC == 4) {
+        asm volatile("" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]), "+v"(fa[2][1]),
+                          "+v"(fa[3][0]), "+v"(fa[3][1]));
+        asm volatile("" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[2][0]), "+v"(fb[2][1]),
+                          "+v"(fb[3][0]), "+v"(fb[3][1]));
+      } else {
+        asm volatile("" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fb[0][0]), "+v"(fb[0][1]),
+                          "+v"(fb[1][0]), "+v"(fb[1][1]));
       }
 #pragma unroll
-      for (int s = 0; s < P::S32; ++s) P::mfma_acc(fa[0][s], fb[0][s], acc);
+      for (int w = 0; w < NSRC; ++w)
+#pragma unroll
+        for (int s = 0; s < P::S32; ++s) P::mfma_acc(fa[w][s], fb[w][s], acc);
+    } else {
+#pragma unroll
+      for (int w = 0; w < NSRC; ++w) {
+#pragma unroll
+        for (int s = 0; s < P::S32; ++s) {
+          fa[0][s] = *(const typename P::frag*)(base + w * X::SLOT_B + (own.n * P::S32 + s) * X::FRAG_B);
+          fb[0][s] = *(const typename P::frag*)(base + w * X::SLOT_B + ((2 + own.m) * P::S32 + s) * X::FRAG_B);
+        }
+#pragma unroll
+        for (int s = 0; s < P::S32; ++s) P::mfma_acc(fa[0][s], fb[0][s], acc);
+      }
     }
   }
   buf ^= 1;
@@ -852,6 +970,9 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
   char* xch = smem;
   char* limg = smem + Xch<P>::BYTES;
   if (WLDS) stage_image(limg, gimg, T::IMG_BYTES);
+  // the exchange image is read in whole 32-feature tiles even where a layer writes fewer: start from zeros, not from
+  // whatever bit patterns the LDS held
+  for (int i = threadIdx.x * 16; i < Xch<P>::BYTES; i += 256 * 16) *(uint4*)(xch + i) = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
   const char* img = WLDS ? (const char*)limg : gimg;
   const float* bias = (const float*)(img + T::BIAS_OFF_ALL);
@@ -903,7 +1024,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
 #pragma unroll
       for (int s = 0; s < P::S8; ++s) dz3[s] = P::from_acc(a, s);
     }
-    exchange_wgrad<P, C3, 2, 1, 2 * P::S32, P::S8>(xch, buf, lane, wv, sv.c2, dz3, acc[C3], bsum + db_base(C3));
+    xch_put<P, 2, 1, 2 * P::S32, P::S8>(xch, buf, lane, wv, sv.c2, dz3, bsum + db_base(C3));  // take: after the next layer's dense
     // ---- C2
     typename P::frag dzc2[2 * P::S32];
     {
@@ -911,7 +1032,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
       dense<P, 2, P::S8, false>(img, T::b_base(C3), nullptr, lane, lofs, dz3, a);
       mask_frags<P, 2>(a, sv.c2, dzc2);
     }
-    exchange_wgrad<P, C2, 2, 2, 2 * P::S32, 2 * P::S32>(xch, buf, lane, wv, sv.c1, dzc2, acc[C2], bsum + db_base(C2));
+    xch_take<P, 2, 1>(xch, buf, lane, wv, acc[C3], bsum + db_base(C3));
+    xch_put<P, 2, 2, 2 * P::S32, 2 * P::S32>(xch, buf, lane, wv, sv.c1, dzc2, bsum + db_base(C2));  // take: after the next layer's dense
     // ---- C1
     typename P::frag dzc1[2 * P::S32];
     {
@@ -919,7 +1041,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
       dense<P, 2, 2 * P::S32, false>(img, T::b_base(C2), nullptr, lane, lofs, dzc2, a);
       mask_frags<P, 2>(a, sv.c1, dzc1);
     }
-    exchange_wgrad<P, C1, 2, 2, P::S32 + P::S8, 2 * P::S32>(xch, buf, lane, wv, sv.cin, dzc1, acc[C1], bsum + db_base(C1));
+    xch_take<P, 2, 2>(xch, buf, lane, wv, acc[C2], bsum + db_base(C2));
+    xch_put<P, 2, 2, P::S32 + P::S8, 2 * P::S32>(xch, buf, lane, wv, sv.cin, dzc1, bsum + db_base(C1));  // take: after the next layer's dense
     // ---- L3: ds rows 1..15 = d cin slots 1..15 ; row 0 = d sigma * lrelu'(s0)
     typename P::frag dz_s[P::S16];
     {
@@ -929,7 +1052,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
 #pragma unroll
       for (int s = 0; s < P::S16; ++s) dz_s[s] = P::from_acc(a[0], s);
     }
-    exchange_wgrad<P, L3, 2, 1, 2 * P::S32, P::S16>(xch, buf, lane, wv, sv.h2, dz_s, acc[L3], bsum + db_base(L3));
+    xch_take<P, 2, 2>(xch, buf, lane, wv, acc[C1], bsum + db_base(C1));
+    xch_put<P, 2, 1, 2 * P::S32, P::S16>(xch, buf, lane, wv, sv.h2, dz_s, bsum + db_base(L3));  // take: after the next layer's dense
     // ---- L2
     typename P::frag dz2[2 * P::S32];
     {
@@ -937,7 +1061,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
       dense<P, 2, P::S16, false>(img, T::b_base(L3), nullptr, lane, lofs, dz_s, a);
       mask_frags<P, 2>(a, sv.h2, dz2);
     }
-    exchange_wgrad<P, L2, 2, 2, 2 * P::S32, 2 * P::S32>(xch, buf, lane, wv, sv.h1, dz2, acc[L2], bsum + db_base(L2));
+    xch_take<P, 2, 1>(xch, buf, lane, wv, acc[L3], bsum + db_base(L3));
+    xch_put<P, 2, 2, 2 * P::S32, 2 * P::S32>(xch, buf, lane, wv, sv.h1, dz2, bsum + db_base(L2));  // take: after the next layer's dense
     // ---- L1
     typename P::frag dz1[2 * P::S32];
     {
@@ -945,7 +1070,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
       dense<P, 2, 2 * P::S32, false>(img, T::b_base(L2), nullptr, lane, lofs, dz2, a);
       mask_frags<P, 2>(a, sv.h1, dz1);
     }
-    exchange_wgrad<P, L1, 1, 2, P::S32, 2 * P::S32>(xch, buf, lane, wv, sv.x0, dz1, acc[L1], bsum + db_base(L1));
+    xch_take<P, 2, 2>(xch, buf, lane, wv, acc[L2], bsum + db_base(L2));
+    xch_put<P, 1, 2, P::S32, 2 * P::S32>(xch, buf, lane, wv, sv.x0, dz1, bsum + db_base(L1));  // take: after the next layer's dense
     // ---- d feat
     if (dfd.p) {
       f32x16 a[1];
@@ -974,6 +1100,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
         }
       }
     }
+    xch_take<P, 1, 2>(xch, buf, lane, wv, acc[L1], bsum + db_base(L1));
   }
 
   // ---- flush: every wave adds its tiles straight to global memory (once per kernel; <= 6 x 16 x 64 atomics per wave)
