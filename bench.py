@@ -86,7 +86,8 @@ def main():
     prec = _lib.BF16 if args.precision == "bf16" else _lib.F32
     fdt = _lib.BF16 if args.feat_dtype == "bf16" else _lib.F32
     total_steps = 4000 * 1000  # train_hash2.py:156-157: epochs * len(loader) (1000 epochs x 4000 batches of the 64M lego rays)
-    tr = HashNeRFTrainer(enc, mlp, near=2.0, far=6.0, num_samples=S, total_steps=total_steps, precision=prec, feat_dtype=fdt)
+    tr = HashNeRFTrainer(enc, mlp, near=2.0, far=6.0, num_samples=S, total_steps=total_steps, precision=prec, feat_dtype=fdt,
+                         overlap_comm=os.environ.get("HBR_OVERLAP_COMM", "1") != "0")  # A/B switch for the staged all-reduce
     torch.manual_seed(1234)  # identical jitter t[S] on every rank
 
     def sync():

@@ -256,11 +256,18 @@ static void launch_bwd(int algo, hipStream_t st, PointSrc ps, uint32_t N, const 
                        stride, g, dtables, lpg);
   } else {
     const int spl = (int)((g.T + kSliceRows - 1) / kSliceRows);
-    // ~2048 workgroups (measured optimum at N = 2M: 512 -> 1.20 ms, 1024 -> 1.02, 2048 -> 0.97, 4096 -> 1.02): with the
-    // chunk index varying fastest and 16 chunks, chunk c of every (level, slice, feature) lands on XCD c % 8, so the
-    // cached coordinates and dy of a chunk are re-read from that XCD's L2; at most one chunk per 1024-point stripe
-    constexpr int kTargetBlocks = 2048;
-    int chunks = (kTargetBlocks + g.L * spl * 2 - 1) / (g.L * spl * 2);
+    // Chunks of ~128 Ki points (measured at N = 2M, L = 16: 4 chunks -> 1.20 ms, 8 -> 1.02, 16 -> 0.97, 32 -> 1.02: a
+    // workgroup's 128 KiB zero + flush must be amortised, yet the grid has to fill 256 CUs several times over).  The
+    // count depends on N, not on L, so a launch over a sub-range of the levels (the staged multi-GPU all-reduce) runs
+    // the same per-workgroup shape as the full one.  With the chunk index varying fastest and a multiple of 8 chunks,
+    // chunk c of every (level, slice, feature) lands on XCD c % 8, so the cached coordinates and dy of a chunk are
+    // re-read from that XCD's L2.  Small problems still get >= 512 workgroups; at most one chunk per 1024-point stripe.
+    constexpr int64_t kChunkPoints = 128 * 1024;
+    constexpr int kMinBlocks = 512;
+    int chunks = (int)((N + kChunkPoints / 2) / kChunkPoints);
+    if (chunks >= 8) chunks = (chunks + 4) / 8 * 8;
+    const int min_chunks = (kMinBlocks + g.L * spl * 2 - 1) / (g.L * spl * 2);
+    if (chunks < min_chunks) chunks = min_chunks;
     int max_chunks = (int)((N + kLdsBwdThreads - 1) / kLdsBwdThreads);
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1) chunks = 1;

@@ -50,6 +50,26 @@ def allreduce_mean_(flat: torch.Tensor, world: int, group=None, scale_in_place: 
     return flat
 
 
+class StagedAllReduce:
+    """The step's gradient all-reduce issued in pieces, each as soon as its slice of the flat buffer is final, so that
+    all but the last piece overlap the kernels still producing the rest (RCCL runs them on its own stream; `launch`
+    orders a piece after everything already enqueued on the caller's current stream, `finish` makes the current stream
+    wait for all of them).  The pieces partition the buffer, so the result is bit-identical to one collective over
+    the whole buffer.  With world == 1 every call is a no-op."""
+
+    def __init__(self, world: int, group=None):
+        self.world, self.group, self._works = world, group, []
+
+    def launch(self, piece: torch.Tensor) -> None:
+        if self.world > 1 and piece.numel():
+            self._works.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self) -> None:
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+
 def broadcast_params_(tensors, src: int = 0, group=None) -> None:
     """Make replicas identical at start-up (the reference relies on DataParallel's replicate each forward)."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:

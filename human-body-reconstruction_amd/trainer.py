@@ -22,6 +22,7 @@ from typing import Optional
 import torch
 
 from . import ops
+from .dist import StagedAllReduce
 from ._lib import BF16, F32, MLP_PARAM_FLOATS, PLANAR
 from .encoder import PositionalEncoder
 from .hash_encoding import HashEncoder
@@ -38,13 +39,14 @@ class HashNeRFTrainer:
     def __init__(self, encoder: HashEncoder, mlp: MLP_3D, near: float = 2.0, far: float = 6.0, num_samples: int = 128,
                  total_steps: int = 100000, lr_embed: float = 0.05, lr_mlp: float = 0.005, eta_min: float = 1e-4,
                  weight_decay_mlp: float = 0.01, precision: int = BF16, feat_dtype: int = F32, num_freq: int = 4,
-                 process_group=None, scatter_algo: int = 0):
+                 process_group=None, scatter_algo: int = 0, overlap_comm: bool = True):
         self.enc, self.mlp = encoder, mlp
         self.near, self.far, self.S = float(near), float(far), int(num_samples)
         self.total_steps = int(total_steps)
         self.lr_embed, self.lr_mlp, self.eta_min, self.wd_mlp = lr_embed, lr_mlp, eta_min, weight_decay_mlp
         self.precision, self.feat_dtype, self.num_freq = precision, feat_dtype, num_freq
         self.scatter_algo = scatter_algo
+        self.overlap_comm = overlap_comm
         self.pg = process_group
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
@@ -99,10 +101,29 @@ class HashNeRFTrainer:
         ops.composite_bwd(t, out.data_ptr(), 4, out.data_ptr() + 12, 4, dn, R, S, dCr, d_out.data_ptr(), d_out.data_ptr() + 12)
         self.grad.zero_()
         dfeat = self._timed("mlp_bwd", lambda: ops.mlp_bwd(feat, PLANAR, pe, S, self.flat, self.precision, d_out, self.g_mlp))
-        self._timed("hash_bwd", lambda: ops.hash_encode_bwd(g, dfeat, self.g_tab, rays=rays, layout=PLANAR, algo=self.scatter_algo))
-        # the one collective of the step
-        if self.world > 1:
-            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        if self.world > 1 and self.overlap_comm and g.L >= 2:
+            # The step's one all-reduce, issued in three pieces that partition the flat gradient buffer: the MLP block
+            # (final after K4), then the upper half of the levels while the lower half's scatter is still running.
+            # Only the last piece (4 MiB at L = 16) is exposed.  Planar [L,N,2] dfeat and [L,T,F] grads make a level
+            # range a contiguous slice, so the same kernel runs on each half.
+            red = StagedAllReduce(self.world, self.pg)
+            nt, half = self.n_tab, g.L // 2
+            cut = half * g.T * g.F
+            red.launch(self.grad[nt:])
+
+            def scatter_halves():  # timed as ONE hash_bwd span (both launches), like the single-launch path
+                for lo, hi, piece in ((half, g.L, self.grad[cut:nt]), (0, half, self.grad[:cut])):
+                    sub = ops.HashGeom(g.scales[lo:hi], g.mu, g.sigma, g.T, g.F)
+                    ops.hash_encode_bwd(sub, dfeat[lo:hi], self.g_tab[lo:hi], rays=rays, layout=PLANAR, algo=self.scatter_algo)
+                    red.launch(piece)
+
+            self._timed("hash_bwd", scatter_halves)
+            red.finish()
+        else:
+            self._timed("hash_bwd", lambda: ops.hash_encode_bwd(g, dfeat, self.g_tab, rays=rays, layout=PLANAR, algo=self.scatter_algo))
+            # the one collective of the step
+            if self.world > 1:
+                torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)
         # optimiser (dense Adam over every table row, as the reference's torch.optim.Adam does)
         k = self.step_count
         gs = 1.0 / self.world

@@ -57,7 +57,18 @@ def _worker(rank, world, port, out_dir):
     shard = hd.shard_batch(batch, rank, world)
     assert shard[0].shape[0] == batch[0].shape[0] // world
     flat = _flat_grad(shard, t, tables, params, scales, mn, sig)
+    # the staged variant the trainer uses for N > 1 (MLP block, upper levels, lower levels): the pieces partition the
+    # buffer, so it must give the very same bits as the single collective
+    staged = flat.clone()
+    red = hd.StagedAllReduce(world)
+    nt = tables.numel()
+    cut = nt // 2
+    for piece in (staged[nt:], staged[cut:nt], staged[:cut]):
+        red.launch(piece)
+    red.finish()
+    staged.mul_(1.0 / world)
     hd.allreduce_mean_(flat, world)
+    assert torch.equal(staged, flat)
     torch.save(flat, os.path.join(out_dir, f"g{rank}.pt"))
     torch.distributed.destroy_process_group()
 
