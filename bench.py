@@ -26,8 +26,12 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
 # algorithmic work per ray-sample (DESIGN.md "Measurement")
-HASH_FWD_BYTES = 12 + 16 * 8 * 2 * 4 + 16 * 2 * 4   # x + 128 gathers of 8 B + y            = 1164 B
-HASH_BWD_BYTES = 12 + 16 * 2 * 4 + 16 * 8 * 2 * 4   # x + dy + 128 scatter-adds of 8 B      = 1164 B
+def hash_fwd_bytes(feat_elem_bytes):   # x + 128 gathers of 8 B + y[32]      = 1164 B (fp32 y) / 1100 B (bf16 y)
+    return 12 + 16 * 8 * 2 * 4 + 16 * 2 * feat_elem_bytes
+
+
+def hash_bwd_bytes(feat_elem_bytes):   # x + dy[32] + 128 scatter-adds of 8 B = 1164 B (fp32 dy) / 1100 B (bf16 dy)
+    return 12 + 16 * 2 * feat_elem_bytes + 16 * 8 * 2 * 4
 MLP_FWD_FLOP = 2 * (32 * 64 + 64 * 64 + 64 * 16 + 39 * 64 + 64 * 64 + 64 * 3)  # 27904
 MLP_BWD_FLOP = 3 * MLP_FWD_FLOP                     # recompute + data grad + weight grad
 
@@ -40,7 +44,8 @@ def main():
     ap.add_argument("--rays", type=int, default=16000, help="rays per rank per step (train_hash2.py:27)")
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--feat-dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--feat-dtype", default="auto", choices=["auto", "f32", "bf16"],
+                    help="storage of the feature / feature-gradient buffers between the hash and MLP kernels (auto: the MLP precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
@@ -84,7 +89,7 @@ def main():
         batches.append(tuple(a.contiguous() for a in (o, d, dn.reshape(-1), gt)))
     enc, denc, mlp = build_default_model(mn, sig, dev, seed=0)  # same init on every rank (replicated parameters)
     prec = _lib.BF16 if args.precision == "bf16" else _lib.F32
-    fdt = _lib.BF16 if args.feat_dtype == "bf16" else _lib.F32
+    fdt = prec if args.feat_dtype == "auto" else (_lib.BF16 if args.feat_dtype == "bf16" else _lib.F32)
     total_steps = 4000 * 1000  # train_hash2.py:156-157: epochs * len(loader) (1000 epochs x 4000 batches of the 64M lego rays)
     tr = HashNeRFTrainer(enc, mlp, near=2.0, far=6.0, num_samples=S, total_steps=total_steps, precision=prec, feat_dtype=fdt,
                          overlap_comm=os.environ.get("HBR_OVERLAP_COMM", "1") != "0")  # A/B switch for the staged all-reduce
@@ -122,9 +127,10 @@ def main():
             kern[name] = sum(a.elapsed_time(b) for a, b in evs) / len(evs)  # ms
     N = R * S
     roofs = {}
+    fb = 2 if fdt == _lib.BF16 else 4  # bytes per stored feature / feature-gradient element
     if kern:
-        roofs["hash_fwd"] = dict(bound="hbm", achieved=HASH_FWD_BYTES * N / (kern["hash_fwd"] * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
-        roofs["hash_bwd"] = dict(bound="hbm", achieved=HASH_BWD_BYTES * N / (kern["hash_bwd"] * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+        roofs["hash_fwd"] = dict(bound="hbm", achieved=hash_fwd_bytes(fb) * N / (kern["hash_fwd"] * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+        roofs["hash_bwd"] = dict(bound="hbm", achieved=hash_bwd_bytes(fb) * N / (kern["hash_bwd"] * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
         roofs["mlp_fwd"] = dict(bound="mfma", achieved=MLP_FWD_FLOP * N / (kern["mlp_fwd"] * 1e-3) / 1e12, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s")
         roofs["mlp_bwd"] = dict(bound="mfma", achieved=MLP_BWD_FLOP * N / (kern["mlp_bwd"] * 1e-3) / 1e12, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s")
         pmc = {}
@@ -177,7 +183,8 @@ def main():
             "dtype": "bf16" if prec == _lib.BF16 else "f32", "data": "synthetic",
             "config": {"workload": "lego-shaped synthetic scene, hash encoding L=16 F=2 T=2^16 N_min=16 N_max=2048, "
                                    f"{R} rays/rank x {S} samples/ray, MLP 32-64-64-16 / 39-64-64-3, fp32 tables, "
-                                   f"{'bf16' if prec == _lib.BF16 else 'fp32'} MLP (MFMA), Adam+AdamW+cosine",
+                                   f"{'bf16' if prec == _lib.BF16 else 'fp32'} MLP (MFMA), "
+                                   f"{'bf16' if fdt == _lib.BF16 else 'fp32'} feature/feature-gradient buffers, Adam+AdamW+cosine",
                        "rays_per_rank": R, "samples_per_ray": S, "global_rays": R * world, "levels": 16, "table_rows": 2 ** 16,
                        "parallelism": f"ray-sharded dp{world}, 1 all-reduce/step" if world > 1 else "single GPU"},
             "loss": loss,

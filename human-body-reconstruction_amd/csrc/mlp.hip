@@ -319,7 +319,8 @@ struct PeSrc {
 // raw per-lane inputs of one 32-point tile; loaded one tile ahead of use in the backward kernel (software prefetch:
 // with one or two waves per SIMD nothing else hides the HBM latency of these loads)
 struct TileIn {
-  float2 v[8];              // (f0,f1) of the lane's 8 levels
+  float2 v[8];              // (f0,f1) of the lane's 8 levels; bf16 storage: .x holds the RAW packed pair, unpacked at use
+                            // (an unpack at load time would wait for the prefetched tile right away)
   float4 peA, peB, peC;     // the lane's 12 direction-encoding values
   float4 dO;                // d out (backward only)
 };
@@ -335,10 +336,10 @@ __device__ __forceinline__ void load_tile_in(const FeatSrc& fs, const PeSrc& ps,
     if (valid) {
       if (LAYOUT == HBR_LAYOUT_PLANAR) {
         if (DT == HBR_F32) ti.v[k] = ((const float2*)fs.p)[(size_t)lvl * fs.N + n];
-        else { uint32_t u = ((const uint32_t*)fs.p)[(size_t)lvl * fs.N + n]; ti.v[k] = make_float2(bf16_lo(u), bf16_hi(u)); }
+        else ti.v[k].x = __uint_as_float(((const uint32_t*)fs.p)[(size_t)lvl * fs.N + n]);
       } else {
         if (DT == HBR_F32) ti.v[k] = *(const float2*)((const float*)fs.p + (size_t)n * fs.stride + 2 * lvl);
-        else { uint32_t u = *(const uint32_t*)((const uint16_t*)fs.p + (size_t)n * fs.stride + 2 * lvl); ti.v[k] = make_float2(bf16_lo(u), bf16_hi(u)); }
+        else ti.v[k].x = __uint_as_float(*(const uint32_t*)((const uint16_t*)fs.p + (size_t)n * fs.stride + 2 * lvl));
       }
     }
   }
@@ -353,20 +354,28 @@ __device__ __forceinline__ void load_tile_in(const FeatSrc& fs, const PeSrc& ps,
 }
 
 // one point's 32 features -> the S32 fragments of the single input tile
-template <class P>
+template <class P, int DT>
 __device__ __forceinline__ void feat_frags(const TileIn& ti, typename P::frag (&x)[P::S32]) {
   if constexpr (P::ELEMS == 8) {
     // step s, element j <-> feature 16s + 8(j>>2) + 4h + (j&3)  == levels 8s+2h, 8s+2h+1, 8s+4+2h, 8s+4+2h+1
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const float2 w[4] = {ti.v[4 * s + 0], ti.v[4 * s + 1], ti.v[4 * s + 2], ti.v[4 * s + 3]};
-      x[s] = PBf16::feat_frag(w);
+      if constexpr (DT == HBR_BF16) {
+        // stored pairs ARE the fragment's words: (f0 | f1 << 16) of the four levels, no conversion
+        const u32x4 w = {__float_as_uint(ti.v[4 * s + 0].x), __float_as_uint(ti.v[4 * s + 1].x),
+                         __float_as_uint(ti.v[4 * s + 2].x), __float_as_uint(ti.v[4 * s + 3].x)};
+        x[s] = __builtin_bit_cast(bf16x8, w);
+      } else {
+        const float2 w[4] = {ti.v[4 * s + 0], ti.v[4 * s + 1], ti.v[4 * s + 2], ti.v[4 * s + 3]};
+        x[s] = PBf16::feat_frag(w);
+      }
     }
   } else {
     // step q <-> feature (q&3) + 8(q>>2) + 4h : level 4(q>>2) + 2h + ((q&3)>>1), component q&1
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const float2 p = ti.v[2 * (q >> 2) + ((q & 3) >> 1)];
+      float2 p = ti.v[2 * (q >> 2) + ((q & 3) >> 1)];
+      if constexpr (DT == HBR_BF16) p = make_float2(bf16_lo(__float_as_uint(p.x)), bf16_hi(__float_as_uint(p.x)));
       x[q] = (q & 1) ? p.y : p.x;
     }
   }
@@ -386,12 +395,12 @@ struct Saved {
 };
 
 
-template <class P>
+template <class P, int DT>  // DT: storage type of the feature buffer the tile was loaded from
 __device__ __forceinline__ void forward_tile(const char* img, const float* bias, const TileIn& ti, int lane, Saved<P>& sv) {
   using T = Tab<P>;
   const int h = lane >> 5;
   const int lofs = opaque_lane_offset<P>(lane);
-  feat_frags<P>(ti, sv.x0);
+  feat_frags<P, DT>(ti, sv.x0);
   const float4 peA = ti.peA, peB = ti.peB, peC = ti.peC;
   {
     f32x16 a[2];
@@ -457,7 +466,7 @@ __global__ __launch_bounds__(kFwdWaves * 64) void mlp_fwd_kernel(const char* __r
     Saved<P> sv;
     TileIn ti;
     load_tile_in<LAYOUT, DT, false>(fs, ps, nullptr, n, valid, lane >> 5, ti);
-    forward_tile<P>(smem, bias, ti, lane, sv);
+    forward_tile<P, DT>(smem, bias, ti, lane, sv);
     if (valid && lane < 32) {
       ((float4*)out)[n] = make_float4(elu1(sv.raw[0]), elu1(sv.raw[1]), elu1(sv.raw[2]), lrelu(sv.s0));
     }
@@ -587,7 +596,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(const char* __rest
       load_tile_in<LAYOUT, DT, true>(fs, ps, dout, nn, tn < ntiles && nn < fs.N, h, nxt);
     }
     Saved<P> sv;
-    forward_tile<P>(img, bias, cur, lane, sv);
+    forward_tile<P, DT>(img, bias, cur, lane, sv);
     const int lofs = opaque_lane_offset<P>(lane);
     const float4 dO = cur.dO;
 
@@ -1008,7 +1017,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
       load_tile_in<LAYOUT, DT, true>(fs, ps, dout, nn, tn < ntiles && nn < fs.N, h, nxt);
     }
     Saved<P> sv;
-    forward_tile<P>(img, bias, cur, lane, sv);
+    forward_tile<P, DT>(img, bias, cur, lane, sv);
     const int lofs = opaque_lane_offset<P>(lane);
     const float4 dO = cur.dO;  // zero on invalid lanes => every dZ of such a point is zero
 

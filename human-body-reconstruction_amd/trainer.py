@@ -38,12 +38,18 @@ def cosine_lr(base_lr: float, eta_min: float, step: int, t_max: int) -> float:
 class HashNeRFTrainer:
     def __init__(self, encoder: HashEncoder, mlp: MLP_3D, near: float = 2.0, far: float = 6.0, num_samples: int = 128,
                  total_steps: int = 100000, lr_embed: float = 0.05, lr_mlp: float = 0.005, eta_min: float = 1e-4,
-                 weight_decay_mlp: float = 0.01, precision: int = BF16, feat_dtype: int = F32, num_freq: int = 4,
+                 weight_decay_mlp: float = 0.01, precision: int = BF16, feat_dtype: Optional[int] = None, num_freq: int = 4,
                  process_group=None, scatter_algo: int = 0, overlap_comm: bool = True):
         self.enc, self.mlp = encoder, mlp
         self.near, self.far, self.S = float(near), float(far), int(num_samples)
         self.total_steps = int(total_steps)
         self.lr_embed, self.lr_mlp, self.eta_min, self.wd_mlp = lr_embed, lr_mlp, eta_min, weight_decay_mlp
+        # Storage type of the planar feature buffer K1 -> K3/K4 and of the feature-gradient buffer K4 -> K2.  Default: the
+        # MLP's precision.  In bf16 mode that is what the MLP reads anyway (its MFMA fragments are bf16, so the forward
+        # is bit-identical to fp32 storage) and what the reference's autocast hands back (the gradient of the Linear
+        # input is produced in half precision and cast up, train_hash2.py:218); it halves 0.8 GB of traffic per step.
+        if feat_dtype is None:
+            feat_dtype = precision
         self.precision, self.feat_dtype, self.num_freq = precision, feat_dtype, num_freq
         self.scatter_algo = scatter_algo
         self.overlap_comm = overlap_comm

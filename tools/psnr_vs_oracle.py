@@ -31,15 +31,17 @@ for name, ac in (() if os.environ.get("SKIP_ORACLE") else (("oracle fp32", False
         C, _, _ = ref_cpu.render(test[0], test[1], t_eval, test[2], tabs, sc, mn, sig, prm)
     res[name] = float(ref_cpu.psnr(C.float(), test[3]))
     print(f"{name:24s} PSNR {res[name]:.2f} dB  ({time.time()-t0:.0f}s)", flush=True)
-for name, prec in (("HIP fp32 run 1", F32), ("HIP fp32 run 2", F32), ("HIP fp32 run 3", F32), ("HIP bf16 run 1", BF16), ("HIP bf16 run 2", BF16)):
+for name, prec, fdt in (("HIP fp32 run 1", F32, F32), ("HIP fp32 run 2", F32, F32), ("HIP fp32 run 3", F32, F32),
+                        ("HIP bf16 (fp32 feature buffers) run 1", BF16, F32), ("HIP bf16 (fp32 feature buffers) run 2", BF16, F32),
+                        ("HIP bf16 (bf16 feature buffers) run 1", BF16, BF16), ("HIP bf16 (bf16 feature buffers) run 2", BF16, BF16)):
     enc, denc, mlp = build_default_model(mn, sig, dev, L=L, T=T, seed=0)
     with torch.no_grad():
         for l in range(L): enc.Embedding_list[l].weight.copy_(tables0[l])
         for k, v in params0.items():
             seq, idx, kind = k.split("."); getattr(getattr(mlp, seq)[int(idx)], kind).copy_(v)
-    tr = HashNeRFTrainer(enc, mlp, num_samples=S, total_steps=steps, precision=prec)
+    tr = HashNeRFTrainer(enc, mlp, num_samples=S, total_steps=steps, precision=prec, feat_dtype=fdt)
     for k in range(steps):
         tr.step(*(a.to(dev) for a in batches[k % 16]), t=ts[k].to(dev))
     C = tr.render(test[0].to(dev), test[1].to(dev), test[2].to(dev), t=t_eval.to(dev))
     res[name] = float(calc_psnr(C.cpu(), test[3]))
-    print(f"{name:24s} PSNR {res[name]:.2f} dB", flush=True)
+    print(f"{name:40s} PSNR {res[name]:.2f} dB", flush=True)

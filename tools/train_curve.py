@@ -11,9 +11,9 @@ o0, d0, _, _ = ref_cpu.synthetic_rays(65536, seed=0)
 mn, mx, sig = ref_cpu.bbox_mu_sigma(o0, d0)
 pool = [ref_cpu.synthetic_scene_rays(R, seed=100 + i, device=dev) for i in range(64)]
 test = ref_cpu.synthetic_scene_rays(R, seed=999, device=dev)
-for prec, name in ((BF16, "bf16"), (F32, "fp32")):
+for prec, fdt, name in ((BF16, BF16, "bf16 MLP, bf16 feature buffers"), (BF16, F32, "bf16 MLP, fp32 feature buffers"), (F32, F32, "fp32")):
     enc, denc, mlp = build_default_model(mn, sig, dev, seed=0)
-    tr = HashNeRFTrainer(enc, mlp, num_samples=S, total_steps=steps, precision=prec)
+    tr = HashNeRFTrainer(enc, mlp, num_samples=S, total_steps=steps, precision=prec, feat_dtype=fdt)
     torch.manual_seed(0)
     t0 = time.time(); line = [name]
     for k in range(steps + 1):
