@@ -71,7 +71,7 @@ int hbr_hash_encode_fwd(const float* x, const float* rays_o, const float* rays_d
  * Replaces autograd of the above (16x aten::embedding_dense_backward + mul/sum backward).
  *   dy       same layout/dtype conventions as y
  *   dtables  [L,T,F] fp32, ACCUMULATED INTO (caller zeroes it when a fresh gradient is wanted)
- *   algo     0 = auto, 1 = global float atomics, 2 = LDS-partitioned accumulate + slab flush
+ *   algo     0 = auto, 1 = global float atomics, 2 = LDS-partitioned fp64 accumulate, atomic flush
  *   ws       optional 16-byte-aligned scratch of hbr_hash_bwd_workspace_bytes() bytes (the LDS-slice algorithm
  *            caches the normalised coordinates there once per call); NULL / too small => recomputed per visit
  */
