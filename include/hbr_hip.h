@@ -115,8 +115,9 @@ int hbr_dir_encode(const float* x, int64_t rows, int d_model, int num_freq, floa
  *            col0.W[64,39] col0.b[64] col2.W[64,64] col2.b[64] col4.W[3,64] col4.b[3]   (14227 floats)
  *   precision HBR_F32 (exact-fp32 MFMA, v_mfma_f32_32x32x2_f32) or HBR_BF16 (bf16 operands, fp32 accumulate)
  *   out      [N,4] fp32 (r,g,b,sigma)
- *   ws       scratch of hbr_mlp_workspace_bytes(precision) bytes, 16-byte aligned (holds the weights
- *            re-packed in MFMA-fragment order; rebuilt on every call, nothing is cached)
+ *   ws       scratch of hbr_mlp_workspace_bytes(precision) bytes (about 28 MB), 16-byte aligned: the weights
+ *            re-packed in MFMA-fragment order (rebuilt on every call, nothing is cached), followed by the
+ *            backward's per-workgroup weight-gradient slabs (written and reduced within one hbr_mlp_bwd call)
  */
 enum { HBR_MLP_PARAM_FLOATS = 14227 };
 int64_t hbr_mlp_workspace_bytes(int precision);
