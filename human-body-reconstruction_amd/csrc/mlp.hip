@@ -777,16 +777,19 @@ __global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(const char* __rest
 constexpr int kSlabRegs = NLAYER * 16 + 10;        // per wave: 6 tiles x 16 registers, then the 10 bias partials
 constexpr int kSlabWave = kSlabRegs * 64;          // floats per wave
 constexpr int kSlabWg = 4 * kSlabWave;             // floats per workgroup (four tile-owning waves)
+static_assert(kSlabWg % 32 == 0, "reduce kernel takes 32 entries per block");
 constexpr int kMaxBwdBlocks = 256;                 // one workgroup per CU
 __device__ __host__ constexpr int64_t slab_offset_bytes(int64_t img_bytes) { return (img_bytes + 255) / 256 * 256; }
 
+// 256 threads = 32 consecutive slab entries x 8 parts; part p sums slabs p, p+8, ... with four loads in flight, the
+// eight partials are combined through LDS in a fixed order (a single thread per entry walking all 256 slabs was
+// latency-bound: 62 us).
 __global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(const float* __restrict__ slabs, int nblocks,
                                                             float* __restrict__ dparams) {
-  const int e = blockIdx.x * 256 + threadIdx.x;  // (wave, register, lane) of the slab layout
-  if (e >= kSlabWg) return;
-  float v = 0.f;
-  for (int b = 0; b < nblocks; ++b) v += slabs[(size_t)b * kSlabWg + e];
-  if (v == 0.f) return;
+  __shared__ float part[8][32];
+  const int el = threadIdx.x & 31, p = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + el;  // (wave, register, lane) of the slab layout; kSlabWg is a multiple of 32
+  // where this slab entry belongs in the flat parameter block (-1: a padding row/column of its tile - never read)
   const int lane = e & 63, r = (e >> 6) % kSlabRegs, wv = e / kSlabWave, h = lane >> 5;
   int off;
   if (r < NLAYER * 16) {
@@ -802,7 +805,24 @@ __global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(const float* __restr
     while (db_base(l) > i) --l;
     off = blog_offset(l, 32 * (i - db_base(l)) + (lane & 31));
   }
-  if (off >= 0) unsafeAtomicAdd(dparams + off, v);  // <= 2 (weights) / 8 (biases) partials per address
+  const float* src = slabs + e;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (off >= 0) {
+    int b = p;
+    for (; b + 24 < nblocks; b += 32) {
+      a0 += src[(size_t)b * kSlabWg];
+      a1 += src[(size_t)(b + 8) * kSlabWg];
+      a2 += src[(size_t)(b + 16) * kSlabWg];
+      a3 += src[(size_t)(b + 24) * kSlabWg];
+    }
+    for (; b < nblocks; b += 8) a0 += src[(size_t)b * kSlabWg];
+  }
+  part[p][el] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (p != 0 || off < 0) return;
+  const float v = ((part[0][el] + part[1][el]) + (part[2][el] + part[3][el])) + ((part[4][el] + part[5][el]) + (part[6][el] + part[7][el]));
+  if (v == 0.f) return;
+  unsafeAtomicAdd(dparams + off, v);  // <= 2 (weights) / 8 (biases) partials per address
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1226,7 +1246,7 @@ static void launch_bwd_fused(uint32_t ntiles, hipStream_t st, const char* img, F
   auto k = mlp_bwd_fused_kernel<P, LAYOUT, DT, WLDS>;
   hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, st, img, fs, ps, dout, dfd, slabs);
-  hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3((kSlabWg + 255) / 256), dim3(256), 0, st, (const float*)slabs, (int)blocks, dparams);
+  hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(kSlabWg / 32), dim3(256), 0, st, (const float*)slabs, (int)blocks, dparams);
 }
 
 template <int LAYOUT, int DT>
