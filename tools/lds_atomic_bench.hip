@@ -29,6 +29,17 @@ __global__ __launch_bounds__(1024) void k(float* out) {
     else if (MODE == 6) atomicMax((int*)&lds[a % kLdsWords], (int)it);
     else if (MODE == 7) atomicAdd((double*)&lds[(a % (kLdsWords / 2)) * 2], (double)v);
     else if (MODE == 8) atomicAdd((unsigned long long*)&lds[(a % (kLdsWords / 2)) * 2], (unsigned long long)(long long)(v * (float)it));
+    else if (MODE >= 10) {
+      // eight atomics per random draw (addresses a ^ k*0x9e5, cheap to derive): amortises the loop's own VALU work,
+      // which is what the single-atomic modes above bottom out on (~7 cycles per iteration)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t ak = (a ^ (k * 0x9e5u)) % (kLdsWords / 2) * 2;
+        if (MODE == 10) atomicAdd((double*)&lds[ak], (double)v);
+        else if (MODE == 11) atomicAdd((unsigned long long*)&lds[ak], (unsigned long long)it);
+        else if (MODE == 12) atomicAdd((unsigned int*)&lds[ak], (unsigned int)it);
+      }
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) out[blockIdx.x] = lds[5];
@@ -50,7 +61,7 @@ void run(const char* name) {
   hipEventSynchronize(e1);
   float ms;
   hipEventElapsedTime(&ms, e0, e1);
-  double wave_instr_per_cu = 16.0 * kIters * ((MODE == 5) ? 2 : 1);
+  double wave_instr_per_cu = 16.0 * kIters * ((MODE == 5) ? 2 : (MODE >= 10 ? 8 : 1));
   double cyc = ms * 1e-3 * 2.4e9 / wave_instr_per_cu;
   printf("%-44s active 1/%d: %8.3f ms  ~%7.1f cycles per wave-instruction per CU (16 waves/CU)\n", name, DIV, ms, cyc);
   hipFree(out);
@@ -66,5 +77,8 @@ int main() {
   run<3, 1>("plain ds_read+add+ds_write b32 (racy)"); run<3, 4>("plain ds_read+add+ds_write b32 (racy)");
   run<4, 1>("plain ds_read+add+ds_write b64 (racy)");
   run<5, 1>("2x ds_add_f32 (pair)"); run<5, 4>("2x ds_add_f32 (pair)");
+  run<10, 1>("8x ds_add_f64 per draw"); run<10, 4>("8x ds_add_f64 per draw"); run<10, 8>("8x ds_add_f64 per draw");
+  run<11, 1>("8x ds_add_u64 per draw"); run<11, 4>("8x ds_add_u64 per draw"); run<11, 8>("8x ds_add_u64 per draw");
+  run<12, 1>("8x ds_add_u32 per draw"); run<12, 4>("8x ds_add_u32 per draw");
   return 0;
 }
