@@ -64,6 +64,30 @@ __device__ __forceinline__ void load_feat(const void* y, uint32_t n, int l, uint
   }
 }
 
+// The same load split in two, for software prefetch: `load_feat_raw` only moves bits (nothing waits for the data),
+// `decode_feat` turns them into the two features when they are consumed.
+template <int LAYOUT, int DTYPE>
+__device__ __forceinline__ uint2 load_feat_raw(const void* y, uint32_t n, int l, uint32_t N, int64_t stride) {
+  size_t off = (LAYOUT == HBR_LAYOUT_PLANAR) ? ((size_t)l * N + n) * 2 : (size_t)n * stride + (size_t)l * 2;
+  if (DTYPE == HBR_F32) {
+    const uint32_t* p = (const uint32_t*)y + off;
+    if (LAYOUT == HBR_LAYOUT_PLANAR) return *(const uint2*)p;
+    return make_uint2(p[0], p[1]);
+  } else {
+    const uint16_t* p = (const uint16_t*)y + off;
+    if (LAYOUT == HBR_LAYOUT_PLANAR) return make_uint2(*(const uint32_t*)p, 0u);  // planar pairs are 4-byte aligned
+    return make_uint2((uint32_t)p[0] | ((uint32_t)p[1] << 16), 0u);
+  }
+}
+template <int DTYPE>
+__device__ __forceinline__ void decode_feat(uint2 raw, float& f0, float& f1) {
+  if (DTYPE == HBR_F32) {
+    f0 = __uint_as_float(raw.x); f1 = __uint_as_float(raw.y);
+  } else {
+    f0 = bf16_lo(raw.x); f1 = bf16_hi(raw.x);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1 forward
 // ------------------------------------------------------------------------------------------------
@@ -180,6 +204,7 @@ __global__ __launch_bounds__(kLdsBwdThreads) void hash_bwd_lds_kernel(PointSrc p
   const int l = (lsf >> 1) / slices_per_level;
 
   for (int i = threadIdx.x; i < kSliceRows; i += kLdsBwdThreads) acc[i] = 0.0;
+  if (POW2 && (uint32_t)(uintptr_t)acc != 0u) __builtin_trap();  // the pow2 path addresses the slice by raw LDS offset
   __syncthreads();
 
   const uint32_t row_lo = slice << kSliceLog2;
@@ -194,34 +219,80 @@ __global__ __launch_bounds__(kLdsBwdThreads) void hash_bwd_lds_kernel(PointSrc p
   // serialise (level 0 cost 3.2x a fine level with the natural mapping).  The stripe's 16 waves together still read
   // every dy cache line completely, so the reads stay L1-friendly.
   const uint32_t perm = (threadIdx.x & 63u) * (kLdsBwdThreads / 64) + (threadIdx.x >> 6);
-  for (uint32_t base = n_begin; base < n_end; base += kLdsBwdThreads) {
-    const uint32_t n = base + perm;
-    if (n >= n_end) continue;
-    float nx, ny, nz, d0, d1;
+  // One stripe ahead: the next visit's coordinates and dy are requested before this visit's arithmetic, so their
+  // latency overlaps it (an iteration was ~2100 cycles per wave, most of it waiting for these two loads at four waves
+  // per SIMD).  The prefetch is unconditional - indices are clamped into range instead of branching around the loads,
+  // because a load inside a divergent branch is waited for at the join - and a clamped (out-of-range) visit is
+  // neutralised by a zero dy.
+  struct Visit { float nx, ny, nz; uint2 raw; bool live; };
+  auto fetch = [&](uint32_t base) {
+    Visit v;
+    v.live = base < n_end && base + perm < n_end;
+    const uint32_t b = base < n_end ? base : n_begin;            // whole stripes: b + threadIdx.x stays inside the cache
+    const uint32_t n = v.live ? base + perm : n_end - 1;         // a valid point index either way
     if (CACHED) {
-      const float* q = xnorm + (size_t)(base + threadIdx.x) * 3;
-      nx = q[0]; ny = q[1]; nz = q[2];
+      const float* q = xnorm + (size_t)(b + threadIdx.x) * 3;
+      v.nx = q[0]; v.ny = q[1]; v.nz = q[2];
     } else {
       float px, py, pz;
       load_point(ps, n, px, py, pz);
-      normalise(g, px, py, pz, nx, ny, nz);
+      normalise(g, px, py, pz, v.nx, v.ny, v.nz);
     }
-    load_feat<LAYOUT, DTYPE>(dy, n, l, N, dy_stride, d0, d1);
-    const float dv = f ? d1 : d0;
+    v.raw = load_feat_raw<LAYOUT, DTYPE>(dy, n, l, N, dy_stride);
+    return v;
+  };
+  if (n_begin >= n_end) return;  // uniform over the workgroup (an empty chunk): nothing to add, nothing to flush
+  Visit nxt = fetch(n_begin);
+  for (uint32_t base = n_begin; base < n_end; base += kLdsBwdThreads) {
+    const Visit cur = nxt;
+    nxt = fetch(base + kLdsBwdThreads);
+    const float nx = cur.nx, ny = cur.ny, nz = cur.nz;
+    float d0, d1;
+    decode_feat<DTYPE>(cur.raw, d0, d1);
+    const float dv = cur.live ? (f ? d1 : d0) : 0.f;
     Cell c = locate(nx, ny, nz, scale);
-    uint32_t rows[8];
-    float w[8];
-    corner_rows<POW2>(g, c, rows);
-    corner_weights(c, w);
+    if constexpr (POW2) {
+      // The loop is VALU-bound (93 instructions per visit, SIMDs 89 % busy with the atomics removed), so the visit is
+      // written for instruction count.  Hash components are pre-shifted by 3 - (h << 3) distributes over ^ and &, and
+      // (c * P) << 3 == c * (P << 3) mod 2^32 - so each corner's masked hash IS its byte offset in the fp64 slice:
+      // one bitop, one subtract, one compare per corner.  The corner weight is split as (x*y) * (z*dy): four xy products
+      // and two z*dy products per visit, converted to fp64 once (6 conversions instead of 8), and the last product is
+      // taken in fp64 inside the predicated part (1 instruction instead of mul, mul, cvt, shift).  The contribution
+      // differs from fl(fl(fl(x*y)*z)*dy) by at most an ulp of fp32 - it is then accumulated in fp64 as before.
+      // Slices are aligned blocks of kSliceRows rows, so with the slice's first byte offset XOR-ed into the y/z terms
+      // the masked hash is < 8*kSliceRows exactly when the row is in the slice, and is then the byte offset inside it.
+      const uint32_t mask8 = g.mask << 3, lo8 = row_lo << 3;
+      const uint32_t x0 = (uint32_t)c.cx << 3, x1 = x0 + 8u;
+      const uint32_t y0 = (uint32_t)c.cy * (kPrimeY << 3), y1 = y0 + (kPrimeY << 3);
+      const uint32_t zz0 = (uint32_t)c.cz * (kPrimeZ << 3), zz1 = zz0 + (kPrimeZ << 3);
+      const uint32_t a[4] = {y0 ^ zz0 ^ lo8, y1 ^ zz0 ^ lo8, y0 ^ zz1 ^ lo8, y1 ^ zz1 ^ lo8};
+      const float gx = __fsub_rn(1.0f, c.fx), gy = __fsub_rn(1.0f, c.fy), gz = __fsub_rn(1.0f, c.fz);
+      const double xy[4] = {(double)__fmul_rn(gx, gy), (double)__fmul_rn(c.fx, gy), (double)__fmul_rn(gx, c.fy),
+                            (double)__fmul_rn(c.fx, c.fy)};
+      const double zd[2] = {(double)__fmul_rn(gz, dv), (double)__fmul_rn(c.fz, dv)};
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      uint32_t rel = rows[k] - row_lo;  // wraps to a huge value when the row is below the slice
-      if (rel < (uint32_t)kSliceRows) {
+      for (int k = 0; k < 8; ++k) {  // corner k: +1 on x / y / z iff bit 0 / 1 / 2 (hash_encoding.py:34-37)
+        const uint32_t off = (((k & 1) ? x1 : x0) ^ a[k >> 1]) & mask8;
+        if (off < (uint32_t)(kSliceRows << 3)) {
+          const double v = xy[k & 3] * zd[k >> 2];
 #ifdef HBR_ABL_NO_DSADD
-        asm volatile("" ::"v"(rel), "v"(__fmul_rn(w[k], dv)));
+          asm volatile("" ::"v"(off), "v"(v));
 #else
-        atomicAdd(&acc[rel], (double)__fmul_rn(w[k], dv));
+          // `acc` is the kernel's only LDS object and sits at LDS address 0 (checked once above), so the offset is the
+          // address: written as asm because the compiler otherwise spends a v_add_u32 per corner adding that zero
+          asm volatile("ds_add_f64 %0, %1" ::"v"(off), "v"(v) : "memory");
 #endif
+        }
+      }
+    } else {
+      uint32_t rows[8];
+      float w[8];
+      corner_rows<POW2>(g, c, rows);
+      corner_weights(c, w);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        uint32_t rel = rows[k] - row_lo;  // wraps to a huge value when the row is below the slice
+        if (rel < (uint32_t)kSliceRows) atomicAdd(&acc[rel], (double)__fmul_rn(w[k], dv));
       }
     }
   }

@@ -1,0 +1,26 @@
+"""Time only the K2 scatter kernel at the BASELINE size, fp32 and bf16 dy (HBR_LIB selects the build under test)."""
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+import torch, ref_cpu
+from hbr_amd import ops
+from hbr_amd._lib import PLANAR
+dev = "cuda:0"
+R, S, L, T = 16000, 128, 16, 2 ** 16
+o, d, dn, gt = ref_cpu.synthetic_rays(R, seed=0)
+mn, mx, sig = ref_cpu.bbox_mu_sigma(o, d)
+sc = ref_cpu.level_scales(16, 2048.0, L)
+geom = ops.HashGeom(tuple(float(v) for v in sc), tuple(float(v) for v in mn), float(sig), T, 2)
+t = ref_cpu.strat_jitter_to_t(2.0, 6.0, S, torch.rand(S)).to(dev)
+rays = (o.to(dev), d.to(dev), t)
+dt = torch.zeros((L, T, 2), device=dev)
+for dtype in (torch.float32, torch.bfloat16):
+    dy = torch.rand((L, R * S, 2), device=dev).to(dtype)
+    for _ in range(3):
+        ops.hash_encode_bwd(geom, dy, dt, rays=rays, layout=PLANAR, algo=2)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        ops.hash_encode_bwd(geom, dy, dt, rays=rays, layout=PLANAR, algo=2)
+    e1.record(); torch.cuda.synchronize()
+    print(os.environ.get("HBR_LIB", "default"), dtype, f"hash_bwd {e0.elapsed_time(e1) / 10:.4f} ms", flush=True)
