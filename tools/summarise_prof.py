@@ -39,5 +39,14 @@ with open(os.path.join(dst, f"{tag}_pmc_hbm.csv"), "w") as f:
         f.write(f"{k},{len(fetch[k])},{fa:.1f},{wa:.1f},{traffic[k]:.0f}\n")
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 line = [l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")][-1]
-open(os.path.join(dst, f"{tag}_bench.json"), "w").write(line)
+# the bench line was printed before this round's PMC passes existed: its `traffic` fields (read from the previous
+# pmc_traffic.json) are refreshed with the numbers just collected, everything else is kept as printed
+rec = json.loads(line)
+for key in ("roofline", "roofline_hash_lookup"):
+    if rec.get(key) and rec[key].get("kernel") in traffic:
+        rec[key]["traffic"] = traffic[rec[key]["kernel"]]
+for k, r in (rec.get("kernels") or {}).items():
+    if k in traffic:
+        r["traffic"] = traffic[k]
+open(os.path.join(dst, f"{tag}_bench.json"), "w").write(json.dumps(rec) + "\n")
 print(open(os.path.join(dst, f"{tag}_pmc_hbm.csv")).read())
