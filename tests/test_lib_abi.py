@@ -29,7 +29,11 @@ def test_header_symbols_all_exported(L):
     assert declared == set(L.SIGNATURES), (declared ^ set(L.SIGNATURES))
     assert lib.hbr_version() == 100
     assert lib.hbr_strerror(-2).decode().startswith("configuration not supported")
-    assert lib.hbr_mlp_workspace_bytes(L.BF16) == (34 + 28) * 1024 + 6 * 64 * 4
+    # MFMA-fragment image of the weights (34 KiB forward + 28 KiB backward + 6 x 64 biases), then one weight-gradient
+    # slab per backward workgroup: 256 workgroups x 4 waves x (6 tiles x 16 + 10 bias) registers x 64 lanes x 4 B
+    img = (34 + 28) * 1024 + 6 * 64 * 4
+    assert img % 256 == 0
+    assert lib.hbr_mlp_workspace_bytes(L.BF16) == img + 256 * 4 * (6 * 16 + 10) * 64 * 4
     assert lib.hbr_mlp_workspace_bytes(L.F32) == (264 + 216) * 256 + 6 * 64 * 4
 
 
