@@ -3,25 +3,29 @@
 on the synthetic lego-shaped scene (BASELINE.json metric; configs[1]: L=16, F=2, T=2^16, 16000 rays x 128 samples,
 bf16 MLP, fp32 tables).
 
-    python bench.py --gpus N --steps K --warmup W
-    (N>1: launched by torch.distributed.run, one rank per GPU; rays are sharded, 16000 rays PER RANK = weak scaling,
-     one RCCL all-reduce of the flat gradient buffer per step)
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
+    N>1: one rank per GPU over RCCL.  Either the driver launches the ranks (torch.distributed.run sets WORLD_SIZE) or,
+    run bare, this script starts them itself (a child `python -m torch.distributed.run ... bench.py ...`) before
+    anything touches the GPU, and relays rank 0's JSON line and exit code.
+    weak (default): 16000 rays PER RANK;  strong: the 16000-ray batch is split over the ranks.
+    One all-reduce of the flat gradient buffer per step either way.
 
 Prints ONE JSON line on rank 0.  Inputs are resident in HBM before the timed region.  `roofline` is measured live
 with HIP events on the launch stream; `cpu_baseline` times the CPU oracle (oracle/ref_cpu.py, a port of the
-reference's PyTorch path) on a bounded sample on rank 0 at N=1 only.
+reference's PyTorch path) on a bounded sample on rank 0 at N=1 only - the only place `oracle/` is imported.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
@@ -36,6 +40,53 @@ MLP_FWD_FLOP = 2 * (32 * 64 + 64 * 64 + 64 * 16 + 39 * 64 + 64 * 64 + 64 * 3)  #
 MLP_BWD_FLOP = 3 * MLP_FWD_FLOP                     # recompute + data grad + weight grad
 
 
+def cpu_baseline(S, mn, sig, total_steps, Rc=4096, budget_s=25.0):
+    """the CPU restatement of the reference's path (oracle/ref_cpu.py - kind "port"; the reference's own
+    files do not travel to the GPU box) timed on this box's host cores: fp32 fwd + bwd + optimiser steps of Rc = 4096
+    rays x S samples of the same scene/config, median of up to 5 steps after one warm-up, on all cores of the box's CPU
+    share and again on 8 threads (the survey's calibration point).  Bounded: each leg stops after `budget_s` seconds
+    (>= 2 steps).  This is the ONLY use of oracle/ in this file."""
+    import statistics
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_cpu
+    try:
+        share = len(os.sched_getaffinity(0))  # the box's CPU share, not os.cpu_count(): oversubscribing a cgroup stalls torch
+    except AttributeError:
+        share = os.cpu_count() or 1
+    oc, dc, dnc, gtc = ref_cpu.synthetic_rays(Rc, seed=77)
+    rng = np.random.default_rng(0)
+    tabs = [torch.from_numpy(rng.uniform(-1e-4, 1e-4, (2 ** 16, 2)).astype(np.float32)).requires_grad_(True) for _ in range(16)]
+    prm = {k: v.requires_grad_(True) for k, v in ref_cpu.mlp_init(0).items()}
+    scales = ref_cpu.level_scales(16, 2048.0, 16)
+    opts = ref_cpu.make_optimizers(tabs, prm.values(), total_steps)
+    tc = ref_cpu.strat_jitter_to_t(2.0, 6.0, S, torch.rand(S))
+    mn_c, sig_c = mn.cpu(), sig.cpu()
+
+    def leg(threads):
+        torch.set_num_threads(threads)
+        print(f"[bench] cpu baseline: {Rc} rays x {S} samples on {threads} threads ...", file=sys.stderr, flush=True)
+        ref_cpu.train_step((oc, dc, dnc, gtc), tc, tabs, scales, mn_c, sig_c, prm, opts)  # warm-up
+        times, c0 = [], time.perf_counter()
+        while len(times) < 5 and (len(times) < 2 or time.perf_counter() - c0 < budget_s):
+            s0 = time.perf_counter()
+            ref_cpu.train_step((oc, dc, dnc, gtc), tc, tabs, scales, mn_c, sig_c, prm, opts)
+            times.append(time.perf_counter() - s0)
+        return Rc * S / statistics.median(times), len(times)
+
+    full = max(1, min(share, 64))
+    v_full, n_full = leg(full)
+    out = dict(value=v_full, unit="ray-samples/s", cores=full, kind="port",
+               sample=f"median of {n_full} fp32 train steps (fwd+bwd+Adam/AdamW) of {Rc} rays x {S} samples, after 1 warm-up "
+                      "(oracle/ref_cpu.py on torch CPU), same scene/config")
+    if full != 8 and share >= 8:
+        v8, n8 = leg(8)
+        out["value_8_threads"] = v8
+        out["sample"] += f"; value_8_threads: median of {n8} steps on 8 threads"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -46,20 +97,31 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--feat-dtype", default="auto", choices=["auto", "f32", "bf16"],
                     help="storage of the feature / feature-gradient buffers between the hash and MLP kernels (auto: the MLP precision)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --rays per rank; strong: --rays in total, split over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Bare `python bench.py --gpus N`: become the launcher.  Nothing has touched the GPU yet (no torch import, no
+        # HIP call), the ranks are CHILD processes, and this process only relays their output and exit code.
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
+
     import torch
-    import ref_cpu
-    from hbr_amd import _lib
+    from hbr_amd import _lib, synthetic
     from hbr_amd.trainer import HashNeRFTrainer, build_default_model
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; the product path has no CPU fallback")
     ndev = torch.cuda.device_count()
@@ -75,17 +137,20 @@ def main():
             torch.distributed.init_process_group(backend)
     assert _lib.lib().hbr_device_ok() == 1, "not a gfx950 device"
 
-    R, S = args.rays, args.samples
+    S = args.samples
+    R = args.rays if args.scaling == "weak" else args.rays // world  # rays per rank per step
+    if R < 1:
+        raise SystemExit("--scaling strong: fewer rays than ranks")
     # ---- synthetic lego-shaped workload, resident in HBM ---------------------------------
     # a pool of pre-shuffled ray batches per rank; the bbox comes from a fixed seed so every rank agrees on it
-    o0, d0, _, _ = ref_cpu.synthetic_rays(65536, seed=0)
-    mn, mx, sig = ref_cpu.bbox_mu_sigma(o0, d0, 2.0, 6.0)
+    o0, d0, _, _ = synthetic.hemisphere_rays(65536, seed=0)
+    mn, mx, sig = synthetic.ray_bbox(o0, d0, 2.0, 6.0)
     pool = 8
     batches = []
     for b in range(pool):
-        # rays toward the object from the upper hemisphere; ground truth = the analytic solid of ref_cpu.analytic_field
+        # rays toward the object from the upper hemisphere; ground truth = the analytic solid of synthetic.solid_field
         # composited on a fine quadrature (a consistent radiance field, so the loss/PSNR of the run mean something)
-        o, d, dn, gt = ref_cpu.synthetic_scene_rays(R, seed=1000 + rank * pool + b, device=dev)
+        o, d, dn, gt = synthetic.scene_rays(R, seed=1000 + rank * pool + b, device=dev)
         batches.append(tuple(a.contiguous() for a in (o, d, dn.reshape(-1), gt)))
     enc, denc, mlp = build_default_model(mn, sig, dev, seed=0)  # same init on every rank (replicated parameters)
     prec = _lib.BF16 if args.precision == "bf16" else _lib.F32
@@ -149,40 +214,16 @@ def main():
     # ---- CPU baseline: the oracle (a port of the reference's PyTorch-CPU path) on a bounded sample ---------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        import numpy as np
-        Rc = 256
-        # the box's CPU share, not os.cpu_count(): oversubscribing a cgroup-limited host stalls torch's thread pool
-        try:
-            ncores = len(os.sched_getaffinity(0))
-        except AttributeError:
-            ncores = os.cpu_count() or 1
-        ncores = max(1, min(ncores, 16))
-        torch.set_num_threads(ncores)
-        print(f"[bench] cpu baseline on {ncores} threads ...", file=sys.stderr, flush=True)
-        oc, dc, dnc, gtc = ref_cpu.synthetic_rays(Rc, seed=77)
-        rng = np.random.default_rng(0)
-        tabs = [torch.from_numpy(rng.uniform(-1e-4, 1e-4, (2 ** 16, 2)).astype(np.float32)).requires_grad_(True) for _ in range(16)]
-        prm = {k: v.requires_grad_(True) for k, v in ref_cpu.mlp_init(0).items()}
-        scales = ref_cpu.level_scales(16, 2048.0, 16)
-        opts = ref_cpu.make_optimizers(tabs, prm.values(), total_steps)
-        tc = ref_cpu.strat_jitter_to_t(2.0, 6.0, S, torch.rand(S))
-        ref_cpu.train_step((oc, dc, dnc, gtc), tc, tabs, scales, mn, sig, prm, opts)  # warm-up
-        n_it, c0 = 0, time.perf_counter()
-        while (n_it < 3 and time.perf_counter() - c0 < 60.0) or (time.perf_counter() - c0 < 10.0 and n_it < 50):
-            ref_cpu.train_step((oc, dc, dnc, gtc), tc, tabs, scales, mn, sig, prm, opts)
-            n_it += 1
-        cdt = time.perf_counter() - c0
-        cpu = dict(value=Rc * S * n_it / cdt, unit="ray-samples/s", cores=torch.get_num_threads(), kind="port",
-                   sample=f"{n_it} fp32 train steps of {Rc} rays x {S} samples (oracle/ref_cpu.py, torch CPU), same scene/config")
+        cpu = cpu_baseline(S, mn, sig, total_steps)
 
     if rank == 0:
         line = {
             "metric": "ray-samples/sec @128 samples/ray on lego (full train step: fwd+bwd+optimiser)",
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "bf16" if prec == _lib.BF16 else "f32", "data": "synthetic",
             "config": {"workload": "lego-shaped synthetic scene, hash encoding L=16 F=2 T=2^16 N_min=16 N_max=2048, "
-                                   f"{R} rays/rank x {S} samples/ray, MLP 32-64-64-16 / 39-64-64-3, fp32 tables, "
+                                   f"{R} rays/rank x {S} samples/ray ({args.scaling} scaling), MLP 32-64-64-16 / 39-64-64-3, fp32 tables, "
                                    f"{'bf16' if prec == _lib.BF16 else 'fp32'} MLP (MFMA), "
                                    f"{'bf16' if fdt == _lib.BF16 else 'fp32'} feature/feature-gradient buffers, Adam+AdamW+cosine",
                        "rays_per_rank": R, "samples_per_ray": S, "global_rays": R * world, "levels": 16, "table_rows": 2 ** 16,

@@ -23,73 +23,78 @@ from torch.utils.data import Dataset
 from .helper import get_od
 
 
-def _resolve(json_path: str, file_path: str, suffix: str) -> str:
-    # dataset.py:22,35: directory of the json + file_path from its first '.' onward (drops a leading '.')
+def _frame_file(json_path: str, file_path: str, suffix: str) -> str:
+    """Image path of a frame: the json's directory joined with `file_path` minus everything up to and including its
+    first '.' (so './train/r_0' -> '<dir>/train/r_0'), plus `suffix` - the reference's rule (dataset.py:22,35),
+    including its requirement that json_path contains a '/'."""
     return json_path[:json_path.rfind('/')] + file_path[file_path.find('.') + 1:] + suffix
 
 
 def _read_rgb(filename: str) -> torch.Tensor:
     from PIL import Image
-    assert os.path.exists(filename), "The file {} does not exist".format(filename)
+    if not os.path.exists(filename):
+        raise AssertionError(f"image file missing: {filename}")
     with Image.open(filename) as im:
         a = np.asarray(im.convert("RGB"), dtype=np.uint8)
     return torch.from_numpy(a).permute(2, 0, 1).float().div(255.0)
 
 
-class NeRF_DATA(Dataset):
+class _TransformsJson(Dataset):
+    """A `transforms*.json` scene: `frames[*]` = {file_path, transform_matrix, <extra>}.  Subclasses say where the
+    intrinsics come from, which suffix image files carry and which per-frame extra is returned third.  The public
+    attributes (`path, data, camera_angle_x, dataset, image_transforms, H, W, focal1, focal2, cx, cy`) are the ones
+    the reference's trainers read (train_hash2.py:58-72)."""
+    suffix = ""
+    extra_key = None
+
     def __init__(self, json_path, transforms=None):
         super().__init__()
-        assert os.path.exists(json_path), "The path {} does not exist".format(json_path)
-        self.path = json_path
-        with open(json_path, "r") as f:
-            self.data = json.load(f)
-        self.camera_angle_x = torch.tensor(self.data["camera_angle_x"])
+        if not os.path.exists(json_path):
+            raise AssertionError(f"scene description missing: {json_path}")
+        self.path, self.image_transforms = json_path, transforms
+        with open(json_path) as fh:
+            self.data = json.load(fh)
         self.dataset = self.data["frames"]
-        self.image_transforms = transforms
-        first = _read_rgb(_resolve(self.path, self.dataset[0]["file_path"], ".png"))
-        self.H, self.W = int(first.shape[1]), int(first.shape[2])
-        focal = self.W / (2 * torch.tan(self.camera_angle_x / 2))
-        self.focal1 = focal
-        self.focal2 = focal
-        self.cx = self.W / 2
-        self.cy = self.H / 2
+        self.camera_angle_x = torch.tensor(self.data["camera_angle_x"])
+        self.H, self.W, self.focal1, self.focal2, self.cx, self.cy = self._camera()
+
+    def _camera(self):
+        raise NotImplementedError
+
+    def frame_path(self, idx: int) -> str:
+        return _frame_file(self.path, self.dataset[idx]["file_path"], self.suffix)
 
     def __len__(self):
         return len(self.dataset)
 
     def __getitem__(self, idx):
         fr = self.dataset[idx]
-        image = _read_rgb(_resolve(self.path, fr["file_path"], ".png"))
+        image = _read_rgb(self.frame_path(idx))
         if self.image_transforms:
             image = self.image_transforms(image)
-        return image, torch.Tensor(fr["transform_matrix"]), fr.get("rotation", 0.0)
+        return image, torch.Tensor(fr["transform_matrix"]), fr.get(self.extra_key, 0.0)
 
 
-class NeRF_DATA_NEW(Dataset):
-    def __init__(self, json_path, transforms=None):
-        super().__init__()
-        assert os.path.exists(json_path), "The path {} does not exist".format(json_path)
-        self.path = json_path
-        with open(json_path, "r") as f:
-            self.data = json.load(f)
-        self.camera_angle_x = torch.tensor(self.data["camera_angle_x"])
-        self.dataset = self.data["frames"]
-        self.image_transforms = transforms
-        self.H, self.W = self.data["h"], self.data["w"]
-        self.focal1 = self.data["fl_x"]
-        self.focal2 = self.data["fl_y"]
-        self.cx = self.data["cx"]
-        self.cy = self.data["cy"]
+class NeRF_DATA(_TransformsJson):
+    """Blender synthetic format (reference dataset.py:9-44): size from the first PNG, one focal length from
+    `camera_angle_x` (:26), principal point at the image centre; third item = `rotation`."""
+    suffix = ".png"
+    extra_key = "rotation"
 
-    def __len__(self):
-        return len(self.dataset)
+    def _camera(self):
+        _, H, W = _read_rgb(self.frame_path(0)).shape
+        focal = W / (2 * torch.tan(self.camera_angle_x / 2))
+        return int(H), int(W), focal, focal, W / 2, H / 2
 
-    def __getitem__(self, idx):
-        fr = self.dataset[idx]
-        image = _read_rgb(_resolve(self.path, fr["file_path"], ""))
-        if self.image_transforms:
-            image = self.image_transforms(image)
-        return image, torch.Tensor(fr["transform_matrix"]), fr.get("sharpness", 0.0)
+
+class NeRF_DATA_NEW(_TransformsJson):
+    """colmap2nerf format (reference dataset_new.py:9-44): `h, w, fl_x, fl_y, cx, cy` from the json, `file_path`
+    already carries its extension; third item = `sharpness`."""
+    extra_key = "sharpness"
+
+    def _camera(self):
+        d = self.data
+        return d["h"], d["w"], d["fl_x"], d["fl_y"], d["cx"], d["cy"]
 
 
 def intrinsics(ds) -> torch.Tensor:

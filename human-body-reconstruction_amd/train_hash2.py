@@ -17,27 +17,37 @@ import numpy as np
 import torch
 
 
+# The reference's flags (train_hash2.py:20-39): names, types and defaults are the contract; the descriptions are ours.
+_REFERENCE_FLAGS = (
+    ("--display", None, None, "accepted for compatibility; there is no GUI preview"),
+    ("--compile", None, None, "accepted for compatibility; the kernels are hand-written HIP, nothing to compile"),
+    ("--load", None, None, "start from {ckpt_name}_Nerf_hash.pth / {ckpt_name}_encoder_hash.pth"),
+    ("--update_rate", int, 15, "occupancy-grid refresh period (the grid is never refreshed, as in the reference)"),
+    ("--write", None, None, "save a test render, both checkpoints and bounds every len(loader)//100 steps"),
+    ("--num_epochs", int, 1000, "passes over the ray set"),
+    ("--num_batch", int, 16000, "rays per optimisation step (split over the ranks)"),
+    ("--num_imgs", int, 2, "unused by this trainer (kept for flag parity)"),
+    ("--num_samples", int, 64, "depth samples per ray"),
+    ("--near", float, 2.0, "first sample depth"),
+    ("--far", float, 6.0, "last stratum's start depth"),
+    ("--plot_grads", None, None, "accepted for compatibility; no plotting"),
+    ("--use_sdf", None, None, "rejected: the SDF branch is outside the accelerated path"),
+    ("--hierarchical", None, None, "add the inverse-CDF second pass (autograd route)"),
+    ("--max_res", float, 2048, "finest grid resolution N_max"),
+    ("--hash_size", float, 16, "log2 of the rows per level"),
+    ("--model_name", str, "default", "prefix of the checkpoints written"),
+    ("--data_path", str, None, "scene directory in colmap2nerf format (default: data/lego/ in Blender format)"),
+    ("--ckpt_name", str, "N_2048_T_16", "prefix of the checkpoints read by --load"),
+)
+
+
 def build_parser():
-    p = argparse.ArgumentParser(description="Train Hashing (MI355X)")
-    p.add_argument("--display", action="store_true", help="(ignored: no GUI)")
-    p.add_argument("--compile", action="store_true", help="(ignored: kernels are hand-written HIP)")
-    p.add_argument("--load", action="store_true", help="Continue from checkpoint")
-    p.add_argument("--update_rate", type=int, default=15, help="Update rate for Occupancy grid (inert, as in the reference)")
-    p.add_argument("--write", action="store_true", help="Write images and checkpoints")
-    p.add_argument("--num_epochs", type=int, default=1000)
-    p.add_argument("--num_batch", type=int, default=16000, help="Ray batch size")
-    p.add_argument("--num_imgs", type=int, default=2)
-    p.add_argument("--num_samples", type=int, default=64, help="Number of samples along ray")
-    p.add_argument("--near", type=float, default=2.0)
-    p.add_argument("--far", type=float, default=6.0)
-    p.add_argument("--plot_grads", action="store_true", help="(ignored)")
-    p.add_argument("--use_sdf", action="store_true", help="(not supported: SDF branch is out of scope)")
-    p.add_argument("--hierarchical", action="store_true", help="Use hierarchical sampling")
-    p.add_argument("--max_res", type=float, default=2048)
-    p.add_argument("--hash_size", type=float, default=16, help="Log size of the hash table")
-    p.add_argument("--model_name", type=str, default="default")
-    p.add_argument("--data_path", type=str, default=None)
-    p.add_argument("--ckpt_name", type=str, default="N_2048_T_16")
+    p = argparse.ArgumentParser(description="hash-NeRF trainer on MI355X (flags of the reference's train_hash2.py)")
+    for flag, typ, default, text in _REFERENCE_FLAGS:
+        if typ is None:
+            p.add_argument(flag, action="store_true", help=text)
+        else:
+            p.add_argument(flag, type=typ, default=default, help=text)
     # additions
     p.add_argument("--synthetic", type=int, default=0, help="train on N synthetic rays instead of a dataset")
     p.add_argument("--steps", type=int, default=0, help="stop after this many optimiser steps (0 = all epochs)")
@@ -50,7 +60,6 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     if args.use_sdf:
         raise NotImplementedError("--use_sdf: the SDF branch is out of scope")
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     from . import _lib, checkpoint, dist as hdist
     from .dataset import NeRF_DATA, NeRF_DATA_NEW, intrinsics, materialise_rays
     from .helper import calc_psnr, find_bounding_box2, get_od
@@ -66,9 +75,9 @@ def main(argv=None):
     # ---- rays (train_hash2.py:50-99) ---------------------------------------------------------------------
     test_rays = None
     if args.synthetic:
-        import ref_cpu  # synthetic workload generator only (numpy RNG); not used for compute
-        rays_o, rays_d, dir_norms, gts = (a.to(dev) for a in ref_cpu.synthetic_rays(args.synthetic, seed=0))
-        test_rays = tuple(a.to(dev) for a in ref_cpu.synthetic_rays(min(args.synthetic, 65536), seed=999))
+        from . import synthetic
+        rays_o, rays_d, dir_norms, gts = (a.to(dev) for a in synthetic.hemisphere_rays(args.synthetic, seed=0))
+        test_rays = tuple(a.to(dev) for a in synthetic.hemisphere_rays(min(args.synthetic, 65536), seed=999))
         H = W = int(np.sqrt(test_rays[0].shape[0]))
     else:
         root = args.data_path if args.data_path is not None else "data/lego/"
