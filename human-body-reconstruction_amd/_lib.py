@@ -21,15 +21,17 @@ SIGNATURES = {
     "hbr_strerror": (C.c_char_p, [_i]),
     "hbr_device_ok": (_i, []),
     "hbr_hash_encode_fwd": (_i, [_p, _p, _p, _p, _l, _l, _p, _p, _p, _f, _i, _l, _i, _p, _i, _l, _i, _p]),
-    "hbr_hash_encode_bwd": (_i, [_p, _p, _p, _p, _l, _l, _p, _i, _l, _i, _p, _p, _f, _i, _l, _i, _p, _i, _p, _l, _p]),
+    "hbr_hash_encode_bwd": (_i, [_p, _p, _p, _p, _l, _l, _p, _i, _l, _i, _p, _p, _p, _f, _i, _l, _i, _p, _i, _p, _l, _p]),
     "hbr_hash_bwd_workspace_bytes": (_l, [_l, _i, _l, _i, _i]),
+    "hbr_hash_bwd_workspace_bytes_min": (_l, [_l, _i, _l, _i, _i]),
     "hbr_composite_fwd": (_i, [_p, _l, _p, _l, _p, _l, _p, _l, _l, _p, _p, _p]),
     "hbr_composite_bwd": (_i, [_p, _l, _p, _l, _p, _l, _p, _l, _l, _p, _p, _p, _p]),
     "hbr_dir_encode": (_i, [_p, _l, _i, _i, _p, _p]),
     "hbr_mlp_workspace_bytes": (_l, [_i]),
     "hbr_mlp_fwd": (_i, [_p, _i, _l, _i, _p, _l, _l, _p, _i, _p, _p, _l, _p]),
     "hbr_mlp_bwd": (_i, [_p, _i, _l, _i, _p, _l, _l, _p, _i, _p, _p, _p, _p, _l, _p]),
-    "hbr_mse2_loss_fwd_bwd": (_i, [_p, _p, _l, _f, _p, _p, _p]),
+    "hbr_mse2_workspace_bytes": (_l, []),
+    "hbr_mse2_loss_fwd_bwd": (_i, [_p, _p, _l, _f, _p, _p, _p, _p]),
     "hbr_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _l, _f, _p]),
 }
 

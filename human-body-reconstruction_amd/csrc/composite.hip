@@ -141,11 +141,16 @@ __global__ __launch_bounds__(kRaysPerBlock * 64) void composite_bwd_kernel(RayIn
   }
 }
 
-// loss = 2*mean((Cr-gt)^2) over R*3 elements; dCr = gscale * 4*(Cr-gt)/(3R)
+// loss = 2*mean((Cr-gt)^2) over R*3 elements; dCr = gscale * 4*(Cr-gt)/(3R).
+// With a scratch block (`partials` [kLossMaxBlocks] floats + one zeroed ticket word behind them) the block sums are
+// parked there and the last block to finish adds them up in block order - a fixed summation order, so the loss is
+// bitwise reproducible - and resets the ticket for the next call.  Without it: one float atomic per block.
+constexpr int kLossMaxBlocks = 1024;
 __global__ __launch_bounds__(256) void mse2_kernel(const float* __restrict__ Cr, const float* __restrict__ gt, int64_t n,
                                                    float inv_n, float gscale, float* __restrict__ loss,
-                                                   float* __restrict__ dCr) {
+                                                   float* __restrict__ dCr, float* __restrict__ partials) {
   __shared__ float part[4];
+  __shared__ bool last;
   float acc = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float d = Cr[i] - gt[i];
@@ -155,7 +160,28 @@ __global__ __launch_bounds__(256) void mse2_kernel(const float* __restrict__ Cr,
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0 && loss) unsafeAtomicAdd(loss, 2.f * inv_n * (part[0] + part[1] + part[2] + part[3]));
+  if (!loss) return;
+  const float mine = (part[0] + part[1]) + (part[2] + part[3]);
+  if (!partials) {
+    if (threadIdx.x == 0) unsafeAtomicAdd(loss, 2.f * inv_n * mine);
+    return;
+  }
+  unsigned* ticket = (unsigned*)(partials + kLossMaxBlocks);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = mine;
+    __threadfence();
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last || threadIdx.x >= 64) return;
+  __threadfence();
+  float s = 0.f;
+  for (unsigned b = threadIdx.x; b < gridDim.x; b += 64) s += __builtin_nontemporal_load(partials + b);  // lane-strided, fixed order
+  s = wave_sum(s);
+  if (threadIdx.x == 0) {
+    *loss += 2.f * inv_n * s;
+    *ticket = 0u;
+  }
 }
 
 static int check_ray_in(const RayIn& in) {
@@ -200,15 +226,17 @@ extern "C" int hbr_composite_bwd(const float* t, int64_t t_stride, const float* 
   return HBR_OK;
 }
 
+extern "C" int64_t hbr_mse2_workspace_bytes(void) { return (kLossMaxBlocks + 1) * (int64_t)sizeof(float); }
+
 extern "C" int hbr_mse2_loss_fwd_bwd(const float* Cr, const float* gt, int64_t R, float gscale, float* loss_out, float* dCr,
-                                     void* stream) {
+                                     void* ws, void* stream) {
   if (!Cr || !gt || R < 0) return HBR_EINVAL;
   if (R == 0) return HBR_OK;
   const int64_t n = R * 3;
   int64_t blocks = (n + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > kLossMaxBlocks) blocks = kLossMaxBlocks;
   hipLaunchKernelGGL(mse2_kernel, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, Cr, gt, n, 1.0f / (float)n, gscale,
-                     loss_out, dCr);
+                     loss_out, dCr, (float*)ws);
   HBR_RETURN_IF_LAUNCH_FAILED();
   return HBR_OK;
 }

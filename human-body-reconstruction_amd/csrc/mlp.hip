@@ -9,11 +9,13 @@
 // 6-layer chain - and the data-gradient chain back - runs in registers with no LDS traffic for activations.
 // One wave owns 32 points at a time.
 //
-// Weight gradients sum over points, i.e. need the point on the K axis.  Instead of staging activations through
-// LDS, each needed tensor is transposed by one more MFMA against an identity operand (exact: every product is
-// x*1 or x*0), which yields "orientation 2" tiles [point in registers][feature on lane] that feed the
-// dW^T = X^T_tile * dZ_tile MFMAs directly.  dW tiles are accumulated in a per-workgroup fp32 LDS image with
-// ds_add_f32 and flushed once per workgroup with contiguous global float atomics.
+// Weight gradients sum over points, i.e. need the point on the K axis (dW^T = X^T_tile * dZ_tile).  The four waves of
+// a workgroup each run the chain for their own 32-point tile and SHARE the 18 dW tiles: a wave parks a layer's X and dZ
+// fragments in an LDS exchange slot, and the tile's owner accumulates over all four slots.  bf16 writes the slot as a
+// [point][feature] image and reads it back with the transposing LDS read (ds_read_b64_tr_b16); exact-fp32 transposes
+// with one more MFMA against an identity operand first (every product is x*1 or x*0).  The owners' accumulators stay in
+// AGPRs for the whole sweep and leave the kernel as per-workgroup slabs that a small reduce kernel sums in a fixed
+// order - no LDS or global float atomics in the loop (ds_add_f32 costs ~190 cycles per wave-instruction on gfx950).
 //
 // Weights are re-packed into MFMA-fragment order by a tiny kernel on every call (parameters are updated in
 // place by the optimiser between calls; nothing is cached across calls), then held in LDS.
@@ -476,17 +478,6 @@ __global__ __launch_bounds__(kFwdWaves * 64) void mlp_fwd_kernel(const char* __r
 // ------------------------------------------------------------------------------------------------
 // backward kernel
 // ------------------------------------------------------------------------------------------------
-constexpr int kDwTiles = 18;  // L1:2 L2:4 L3:2 C1:4 C2:4 C3:2
-#ifndef HBR_BWD_SPLIT
-#define HBR_BWD_SPLIT 0  // 0: single pass with shared dW tiles (mlp_bwd_fused_kernel); 2/3: per-wave dW tiles, 2 or 3 launches
-#endif
-__device__ __host__ constexpr int dw_tile_base(int l) {
-  constexpr int b[NLAYER] = {0, 2, 6, 8, 12, 16};
-  return b[l];
-}
-constexpr int kDwBytes = kDwTiles * 16 * 64 * 4;
-constexpr int kDbBytes = NLAYER * 64 * 4;
-
 // orientation-2 fragments of a tensor given its orientation-1 fragments: xt[tile][s'] (k = points).
 // `colsum[t]` (optional) receives the lane's sum over its 16 point registers of tile t, taken from the fp32 tile
 // before it is re-packed - the bias gradient, without unpacking bf16 again.
@@ -512,32 +503,10 @@ __device__ __forceinline__ void transpose_frags(const typename P::frag (&x)[NK],
   }
 }
 
-// Persistent per-wave weight-gradient accumulators.  LDS float atomics (ds_add_f32) cost ~190 cycles per
-// wave-instruction on gfx950 (measured, tools/lds_atomic_bench.hip; ds_add_u32 ~7, ds_add_f64 ~21), so the dW tiles
-// are NOT accumulated in LDS per point tile: each wave keeps its dW^T tiles in registers across its whole sweep of
-// point tiles (the wgrad MFMA accumulates straight into them) and adds them to the workgroup's LDS image once.
-struct DwAcc {
-  f32x16 t[kDwTiles];
-  float b[10];  // bias grads: L1:0,1 L2:2,3 L3:4 C1:5,6 C2:7,8 C3:9
-};
+// bias-gradient partials of a wave: L1:0,1 L2:2,3 L3:4 C1:5,6 C2:7,8 C3:9
 __device__ __host__ constexpr int db_base(int l) {
   constexpr int b[NLAYER] = {0, 2, 4, 5, 7, 9};
   return b[l];
-}
-
-// dW^T tiles of one layer: [in tile n][out tile m] += XT[n] (A, k = points) x dZT[m] (B)
-template <class P, int LAYER, int NIN, int NOUT>
-__device__ __forceinline__ void wgrad(DwAcc& A, const typename P::frag (&xt)[NIN][P::S32],
-                                      const typename P::frag (&dzt)[NOUT][P::S32]) {
-#pragma unroll
-  for (int n = 0; n < NIN; ++n) {
-#pragma unroll
-    for (int m = 0; m < NOUT; ++m) {
-#pragma unroll
-      for (int s = 0; s < P::S32; ++s)
-        P::mfma_acc(xt[n][s], dzt[m][s], A.t[dw_tile_base(LAYER) + n * NOUT + m]);
-    }
-  }
 }
 
 struct DFeatDst {
@@ -545,235 +514,14 @@ struct DFeatDst {
   int64_t stride;
 };
 
-// WMASK (bit l = layer l) selects which layers' weight gradients this launch produces: their dW tiles live in
-// registers for the whole sweep.  Back-propagation stops below the shallowest selected layer; the launch that
-// selects L1 also writes d feat.
-template <class P, int LAYOUT, int DT, int NWAVES, bool WLDS, int WMASK>
-__global__ __launch_bounds__(NWAVES * 64) void mlp_bwd_kernel(const char* __restrict__ gimg, FeatSrc fs, PeSrc ps,
-                                                              const float* __restrict__ dout, DFeatDst dfd,
-                                                              float* __restrict__ dparams) {
-  using T = Tab<P>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* dw = (float*)smem;
-  float* db = (float*)(smem + kDwBytes);
-  char* limg = smem + kDwBytes + kDbBytes;
-  for (int i = threadIdx.x; i < (kDwBytes + kDbBytes) / 4; i += NWAVES * 64) dw[i] = 0.f;
-  if (WLDS) stage_image(limg, gimg, T::IMG_BYTES);
-  __syncthreads();
-  const char* img = WLDS ? (const char*)limg : gimg;
-  const float* bias = (const float*)(img + T::BIAS_OFF_ALL);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5;
-  const uint32_t ntiles = (fs.N + 31) / 32;
-  constexpr bool wC3 = (WMASK >> C3) & 1, wC2 = (WMASK >> C2) & 1, wC1 = (WMASK >> C1) & 1;
-  constexpr bool wL3 = (WMASK >> L3) & 1, wL2 = (WMASK >> L2) & 1, wL1 = (WMASK >> L1) & 1;
-  // how far back the data gradient has to travel for the selected layers
-  constexpr bool needC2 = WMASK & ((1 << C2) | (1 << C1) | (1 << L3) | (1 << L2) | (1 << L1));
-  constexpr bool needC1 = WMASK & ((1 << C1) | (1 << L3) | (1 << L2) | (1 << L1));
-  constexpr bool needL3 = WMASK & ((1 << L3) | (1 << L2) | (1 << L1));
-  constexpr bool needL2 = WMASK & ((1 << L2) | (1 << L1));
-  constexpr bool needL1 = WMASK & (1 << L1);
-  DwAcc A;
-#pragma unroll
-  for (int i = 0; i < kDwTiles; ++i)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) A.t[i][q] = 0.f;
-#pragma unroll
-  for (int i = 0; i < 10; ++i) A.b[i] = 0.f;
-
-  TileIn nxt;
-  {
-    const uint32_t t0 = blockIdx.x * NWAVES + wv;
-    const uint32_t n0 = t0 * 32 + (lane & 31);
-    load_tile_in<LAYOUT, DT, true>(fs, ps, dout, n0, t0 < ntiles && n0 < fs.N, h, nxt);
-  }
-  for (uint32_t tile = blockIdx.x * NWAVES + wv; tile < ntiles; tile += gridDim.x * NWAVES) {
-    const uint32_t n = tile * 32 + (lane & 31);
-    const bool valid = n < fs.N;
-    const TileIn cur = nxt;
-    {  // issue the next tile's loads now; they are consumed one iteration later
-      const uint32_t tn = tile + gridDim.x * NWAVES;
-      const uint32_t nn = tn * 32 + (lane & 31);
-      load_tile_in<LAYOUT, DT, true>(fs, ps, dout, nn, tn < ntiles && nn < fs.N, h, nxt);
-    }
-    Saved<P> sv;
-    forward_tile<P, DT>(img, bias, cur, lane, sv);
-    const int lofs = opaque_lane_offset<P>(lane);
-    const float4 dO = cur.dO;
-
-    // ---- C3: dZc3 rows 0..2 = d rgb * elu'(raw)  (elu' = 1 for x>0 else exp(x))
-    typename P::frag dz3[P::S8];
-    {
-      f32x16 a;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) a[q] = 0.f;
-      a[0] = dO.x * (sv.raw[0] > 0.f ? 1.f : expf(sv.raw[0]));
-      a[1] = dO.y * (sv.raw[1] > 0.f ? 1.f : expf(sv.raw[1]));
-      a[2] = dO.z * (sv.raw[2] > 0.f ? 1.f : expf(sv.raw[2]));
-#pragma unroll
-      for (int s = 0; s < P::S8; ++s) dz3[s] = P::from_acc(a, s);
-    }
-    if (wC3) {
-      typename P::frag xt[2][P::S32], zt[1][P::S32];
-      transpose_frags<P, 2, 2 * P::S32, false>(sv.c2, lane, xt);
-      transpose_frags<P, 1, P::S8, true>(dz3, lane, zt, A.b + db_base(C3));
-      wgrad<P, C3, 2, 1>(A, xt, zt);
-    }
-    if (needC2) {
-      // ---- C2
-      typename P::frag dzc2[2 * P::S32];
-      {
-        f32x16 a[2];
-        dense<P, 2, P::S8, false>(img, T::b_base(C3), nullptr, lane, lofs, dz3, a);
-        mask_frags<P, 2>(a, sv.c2, dzc2);
-        if (wC2) {
-          typename P::frag xt[2][P::S32], zt[2][P::S32];
-          transpose_frags<P, 2, 2 * P::S32, false>(sv.c1, lane, xt);
-          transpose_frags<P, 2, 2 * P::S32, true>(dzc2, lane, zt, A.b + db_base(C2));
-          wgrad<P, C2, 2, 2>(A, xt, zt);
-        }
-      }
-      if (needC1) {
-        // ---- C1
-        typename P::frag dzc1[2 * P::S32];
-        {
-          f32x16 a[2];
-          dense<P, 2, 2 * P::S32, false>(img, T::b_base(C2), nullptr, lane, lofs, dzc2, a);
-          mask_frags<P, 2>(a, sv.c1, dzc1);
-          if (wC1) {
-            typename P::frag xt[2][P::S32], zt[2][P::S32];
-            transpose_frags<P, 2, P::S32 + P::S8, false>(sv.cin, lane, xt);
-            transpose_frags<P, 2, 2 * P::S32, true>(dzc1, lane, zt, A.b + db_base(C1));
-            wgrad<P, C1, 2, 2>(A, xt, zt);
-          }
-        }
-        if (needL3) {
-          // ---- L3: ds rows 1..15 = d cin slots 1..15 ; row 0 = d sigma * lrelu'(s0)
-          typename P::frag dz_s[P::S16];
-          {
-            f32x16 a[1];
-            dense<P, 1, 2 * P::S32, false>(img, T::b_base(C1), nullptr, lane, lofs, dzc1, a);
-            if (h == 0) a[0][0] = dO.w * (sv.s0 > 0.f ? 1.f : 0.01f);
-#pragma unroll
-            for (int s = 0; s < P::S16; ++s) dz_s[s] = P::from_acc(a[0], s);
-            if (wL3) {
-              typename P::frag xt[2][P::S32], zt[1][P::S32];
-              transpose_frags<P, 2, 2 * P::S32, false>(sv.h2, lane, xt);
-              transpose_frags<P, 1, P::S16, true>(dz_s, lane, zt, A.b + db_base(L3));
-              wgrad<P, L3, 2, 1>(A, xt, zt);
-            }
-          }
-          if (needL2) {
-            // ---- L2
-            typename P::frag dz2[2 * P::S32];
-            {
-              f32x16 a[2];
-              dense<P, 2, P::S16, false>(img, T::b_base(L3), nullptr, lane, lofs, dz_s, a);
-              mask_frags<P, 2>(a, sv.h2, dz2);
-              if (wL2) {
-                typename P::frag xt[2][P::S32], zt[2][P::S32];
-                transpose_frags<P, 2, 2 * P::S32, false>(sv.h1, lane, xt);
-                transpose_frags<P, 2, 2 * P::S32, true>(dz2, lane, zt, A.b + db_base(L2));
-                wgrad<P, L2, 2, 2>(A, xt, zt);
-              }
-            }
-            if (needL1) {
-              // ---- L1
-              typename P::frag dz1[2 * P::S32];
-              {
-                f32x16 a[2];
-                dense<P, 2, 2 * P::S32, false>(img, T::b_base(L2), nullptr, lane, lofs, dz2, a);
-                mask_frags<P, 2>(a, sv.h1, dz1);
-                typename P::frag xt[1][P::S32], zt[2][P::S32];
-                transpose_frags<P, 1, P::S32, false>(sv.x0, lane, xt);
-                transpose_frags<P, 2, 2 * P::S32, true>(dz1, lane, zt, A.b + db_base(L1));
-                wgrad<P, L1, 1, 2>(A, xt, zt);
-              }
-              // ---- d feat
-              if (dfd.p) {
-                f32x16 a[1];
-                dense<P, 1, 2 * P::S32, false>(img, T::b_base(L1), nullptr, lane, lofs, dz1, a);
-                if (valid) {
-#pragma unroll
-                  for (int g = 0; g < 4; ++g) {
-                    // registers 4g..4g+3 <-> features 8g+4h .. 8g+4h+3 = levels 4g+2h, 4g+2h+1
-                    const float v0 = a[0][4 * g], v1 = a[0][4 * g + 1], v2 = a[0][4 * g + 2], v3 = a[0][4 * g + 3];
-                    const int lvl = 4 * g + 2 * h;
-                    if (LAYOUT == HBR_LAYOUT_PLANAR) {
-                      if (DT == HBR_F32) {
-                        ((float2*)dfd.p)[(size_t)lvl * fs.N + n] = make_float2(v0, v1);
-                        ((float2*)dfd.p)[(size_t)(lvl + 1) * fs.N + n] = make_float2(v2, v3);
-                      } else {
-                        ((uint32_t*)dfd.p)[(size_t)lvl * fs.N + n] = pack_bf16x2(v0, v1);
-                        ((uint32_t*)dfd.p)[(size_t)(lvl + 1) * fs.N + n] = pack_bf16x2(v2, v3);
-                      }
-                    } else {
-                      if (DT == HBR_F32) {
-                        *(float4*)((float*)dfd.p + (size_t)n * dfd.stride + 2 * lvl) = make_float4(v0, v1, v2, v3);
-                      } else {
-                        uint2 u = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
-                        *(uint2*)((uint16_t*)dfd.p + (size_t)n * dfd.stride + 2 * lvl) = u;
-                      }
-                    }
-                  }
-                }
-              }
-            }
-          }
-        }
-      }
-    }
-  }
-
-  asm volatile("s_nop 15" ::: "memory");  // last asm MFMA's D -> first non-MFMA reader (12 wait states, 5.7 item 2)
-  // ---- each wave adds its register accumulators to the workgroup image once (ds_add_f32, off the hot loop)
-#pragma unroll
-  for (int l = 0; l < NLAYER; ++l) {
-    if (!((WMASK >> l) & 1)) continue;
-    const int nt = ((l == L3 || l == C3) ? 1 : 2) * ((l == L1) ? 1 : 2);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (i >= nt) continue;
-      float* t = dw + ((dw_tile_base(l) + i) * 16) * 64 + lane;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) atomicAdd(t + q * 64, A.t[dw_tile_base(l) + i][q]);
-    }
-    const int nb = (l == L3 || l == C3) ? 1 : 2;
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      if (m < nb) atomicAdd(db + l * 64 + 32 * m + (lane & 31), A.b[db_base(l) + m]);
-    }
-  }
-
-  // ---- flush the workgroup's dW / db image
-  __syncthreads();
-  for (int e = threadIdx.x; e < kDwTiles * 16 * 64; e += NWAVES * 64) {
-    const float v = dw[e];
-    if (v == 0.f) continue;
-    const int ln = e & 63, q = (e >> 6) & 15, tid = e >> 10;
-    int l = NLAYER - 1;
-    while (dw_tile_base(l) > tid) --l;
-    const int nout = (l == L3 || l == C3) ? 1 : 2;
-    const int nin_t = (tid - dw_tile_base(l)) / nout, mout_t = (tid - dw_tile_base(l)) % nout;
-    const int i = 32 * nin_t + acc_row(q, ln >> 5), o = 32 * mout_t + (ln & 31);
-    const int off = wlog_offset(l, o, i);
-    if (off >= 0) unsafeAtomicAdd(dparams + off, v);
-  }
-  for (int e = threadIdx.x; e < NLAYER * 64; e += NWAVES * 64) {
-    const int off = blog_offset(e / 64, e % 64);
-    const float v = db[e];
-    if (off >= 0 && v != 0.f) unsafeAtomicAdd(dparams + off, v);
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // weight-gradient flush: per-workgroup slabs + one reduce launch
 // ------------------------------------------------------------------------------------------------
-// Adding every wave's tiles to dparams with global float atomics put 6.3 M atomics onto the same 14 227 addresses
-// (1024 waves x 6 tiles x 1024 lanes-registers): 0.20 ms of a 0.61 ms kernel, independent of N (measured: the kernel
-// without its flush, and the kernel's time against N - 0.23 ms intercept).  Instead every wave stores its accumulator
+// Adding every wave's tiles to dparams with global float atomics would put 6.3 M atomics onto the same 14 227 addresses
+// (1024 waves x 6 tiles x 1024 lanes-registers): measured 0.20 ms of a 0.61 ms kernel, independent of N.  Instead every wave stores its accumulator
 // registers as they stand (coalesced 256-B rows) into its workgroup's slab of the caller's workspace, and
-// mlp_dw_reduce_kernel sums the slabs in a fixed order (which also makes the MLP gradient run-to-run reproducible up
-// to the final pair/octet of atomics per address) and adds the result into dparams.
+// mlp_dw_reduce_kernel sums the slabs in a fixed order (which also makes the MLP gradient run-to-run reproducible)
+// and adds the result into dparams.
 constexpr int kSlabRegs = NLAYER * 16 + 10;        // per wave: 6 tiles x 16 registers, then the 10 bias partials
 constexpr int kSlabWave = kSlabRegs * 64;          // floats per wave
 constexpr int kSlabWg = 4 * kSlabWave;             // floats per workgroup (four tile-owning waves)
@@ -783,15 +531,20 @@ __device__ __host__ constexpr int64_t slab_offset_bytes(int64_t img_bytes) { ret
 
 // 256 threads = 32 consecutive slab entries x 8 parts; part p sums slabs p, p+8, ... with four loads in flight, the
 // eight partials are combined through LDS in a fixed order (a single thread per entry walking all 256 slabs was
-// latency-bound: 62 us).
+// latency-bound: 62 us).  Several slab entries can stand for the same parameter - the two waves that share a tile of a
+// two-tile layer, and the 4 waves x 2 lane halves that hold partial sums of one bias row - so ONE of them (the
+// "leader": the even wave / wave 0's lower half) also walks its siblings, in a fixed order, and the others return:
+// every parameter has exactly one writer and one summation order, i.e. the MLP gradient is bitwise reproducible.
 __global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(const float* __restrict__ slabs, int nblocks,
                                                             float* __restrict__ dparams) {
   __shared__ float part[8][32];
   const int el = threadIdx.x & 31, p = threadIdx.x >> 5;
   const int e = blockIdx.x * 32 + el;  // (wave, register, lane) of the slab layout; kSlabWg is a multiple of 32
-  // where this slab entry belongs in the flat parameter block (-1: a padding row/column of its tile - never read)
+  // where this slab entry belongs in the flat parameter block (-1: a padding row/column of its tile, or a sibling
+  // that its leader sums - never read here)
   const int lane = e & 63, r = (e >> 6) % kSlabRegs, wv = e / kSlabWave, h = lane >> 5;
-  int off;
+  int off, nsib = 1, sib_stride = 0;  // siblings: entries e + k * sib_stride (+ 32 for the upper lane half of a bias)
+  bool bias = false;
   if (r < NLAYER * 16) {
     const int l = r >> 4, q = r & 15;
     const int nout = (l == L3 || l == C3) ? 1 : 2;
@@ -799,37 +552,47 @@ __global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(const float* __restr
     const int tau = (tiles == 4) ? wv : (wv >> 1);
     const int nin_t = tau / nout, mout_t = tau % nout;
     off = wlog_offset(l, 32 * mout_t + (lane & 31), 32 * nin_t + acc_row(q, h));
+    if (tiles != 4) {
+      if (wv & 1) off = -1;
+      nsib = 2; sib_stride = kSlabWave;
+    }
   } else {
     const int i = r - NLAYER * 16;  // bias partial i: layer l, out tile m (db_base)
     int l = NLAYER - 1;
     while (db_base(l) > i) --l;
-    off = blog_offset(l, 32 * (i - db_base(l)) + (lane & 31));
+    off = (wv == 0 && h == 0) ? blog_offset(l, 32 * (i - db_base(l)) + (lane & 31)) : -1;
+    bias = true; nsib = 4; sib_stride = kSlabWave;
   }
-  const float* src = slabs + e;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  float tot = 0.f;
   if (off >= 0) {
-    int b = p;
-    for (; b + 24 < nblocks; b += 32) {
-      a0 += src[(size_t)b * kSlabWg];
-      a1 += src[(size_t)(b + 8) * kSlabWg];
-      a2 += src[(size_t)(b + 16) * kSlabWg];
-      a3 += src[(size_t)(b + 24) * kSlabWg];
+    for (int k = 0; k < nsib; ++k) {
+      for (int hh = 0; hh < (bias ? 2 : 1); ++hh) {
+        const float* src = slabs + e + k * sib_stride + 32 * hh;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int b = p;
+        for (; b + 24 < nblocks; b += 32) {
+          a0 += src[(size_t)b * kSlabWg];
+          a1 += src[(size_t)(b + 8) * kSlabWg];
+          a2 += src[(size_t)(b + 16) * kSlabWg];
+          a3 += src[(size_t)(b + 24) * kSlabWg];
+        }
+        for (; b < nblocks; b += 8) a0 += src[(size_t)b * kSlabWg];
+        tot += (a0 + a1) + (a2 + a3);
+      }
     }
-    for (; b < nblocks; b += 8) a0 += src[(size_t)b * kSlabWg];
   }
-  part[p][el] = (a0 + a1) + (a2 + a3);
+  part[p][el] = tot;
   __syncthreads();
   if (p != 0 || off < 0) return;
   const float v = ((part[0][el] + part[1][el]) + (part[2][el] + part[3][el])) + ((part[4][el] + part[5][el]) + (part[6][el] + part[7][el]));
-  if (v == 0.f) return;
-  unsafeAtomicAdd(dparams + off, v);  // <= 2 (weights) / 8 (biases) partials per address
+  dparams[off] += v;  // the only writer of this address
 }
 
 // ------------------------------------------------------------------------------------------------
 // backward kernel, single pass: the four waves of a workgroup SHARE the weight-gradient accumulators
 // ------------------------------------------------------------------------------------------------
-// mlp_bwd_kernel above needs two launches because one wave cannot hold all 18 dW tiles (288 registers) next to its
-// working set.  Here every wave still runs the whole chain for its own 32-point tile, but owns only ONE dW tile per
+// One wave cannot hold all 18 dW tiles (288 registers) next to its working set.  Here every wave runs the whole chain
+// for its own 32-point tile, but owns only ONE dW tile per
 // layer (<= 6 tiles = 96 accumulator registers): it parks a layer's X and dZ fragments in an LDS exchange slot
 // (xch_put), runs the next layer's dense while the others catch up, then the workgroup meets at a barrier and each
 // wave accumulates ITS tile of that layer over the fragments of all four waves (xch_take; K = 128 points per round).
@@ -1208,71 +971,43 @@ static int pack(const float* params, char* ws, hipStream_t st) {
   return HBR_OK;
 }
 
-template <class P, int LAYOUT>
-static void launch_fwd(int dt, uint32_t blocks, hipStream_t st, const char* img, FeatSrc fs, PeSrc ps, float* out) {
-  using T = Tab<P>;
-  const int lds = T::BIAS_OFF_F + T::BIAS_BYTES;
-  if (dt == HBR_F32) {
-    auto k = mlp_fwd_kernel<P, LAYOUT, HBR_F32>;
-    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(k, dim3(blocks), dim3(kFwdWaves * 64), lds, st, img, fs, ps, out);
-  } else {
-    auto k = mlp_fwd_kernel<P, LAYOUT, HBR_BF16>;
-    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(k, dim3(blocks), dim3(kFwdWaves * 64), lds, st, img, fs, ps, out);
-  }
+// raise the kernel's dynamic-LDS limit (above 64 KiB needs the attribute) and launch; a refused attribute is an error,
+// not something to find out from a failed launch later
+template <class K, class... Args>
+static int launch_with_lds(K k, dim3 grid, dim3 block, int lds, hipStream_t st, Args... args) {
+  if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return HBR_ELAUNCH;
+  hipLaunchKernelGGL(k, grid, block, lds, st, args...);
+  return HBR_OK;
 }
 
-template <class P, int LAYOUT, int DT, int NWAVES, bool WLDS, int WMASK>
-static void launch_bwd1(uint32_t ntiles, hipStream_t st, const char* img, FeatSrc fs, PeSrc ps, const float* dout, DFeatDst dfd,
-                        float* dparams) {
+template <class P, int LAYOUT>
+static int launch_fwd(int dt, uint32_t blocks, hipStream_t st, const char* img, FeatSrc fs, PeSrc ps, float* out) {
   using T = Tab<P>;
-  const int lds = kDwBytes + kDbBytes + (WLDS ? T::IMG_BYTES : 0);
-  uint32_t blocks = (ntiles + NWAVES - 1) / NWAVES;
-  if (blocks > 256) blocks = 256;  // one workgroup per CU (LDS-bound); each sweeps its share of the tiles
-  auto k = mlp_bwd_kernel<P, LAYOUT, DT, NWAVES, WLDS, WMASK>;
-  hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL(k, dim3(blocks), dim3(NWAVES * 64), lds, st, img, fs, ps, dout, dfd, dparams);
+  const int lds = T::BIAS_OFF_F + T::BIAS_BYTES;
+  if (dt == HBR_F32) return launch_with_lds(mlp_fwd_kernel<P, LAYOUT, HBR_F32>, dim3(blocks), dim3(kFwdWaves * 64), lds, st, img, fs, ps, out);
+  return launch_with_lds(mlp_fwd_kernel<P, LAYOUT, HBR_BF16>, dim3(blocks), dim3(kFwdWaves * 64), lds, st, img, fs, ps, out);
 }
 
 template <class P, int LAYOUT, int DT, bool WLDS>
-static void launch_bwd_fused(uint32_t ntiles, hipStream_t st, const char* img, FeatSrc fs, PeSrc ps, const float* dout,
-                             DFeatDst dfd, float* dparams) {
+static int launch_bwd_fused(uint32_t ntiles, hipStream_t st, const char* img, FeatSrc fs, PeSrc ps, const float* dout,
+                            DFeatDst dfd, float* dparams) {
   using T = Tab<P>;
   const int lds = Xch<P>::BYTES + (WLDS ? T::IMG_BYTES : 0);
   uint32_t blocks = (ntiles + 3) / 4;
   if (blocks > kMaxBwdBlocks) blocks = kMaxBwdBlocks;  // one workgroup per CU; each sweeps its share of the tiles in rounds of four
   float* slabs = (float*)(const_cast<char*>(img) + slab_offset_bytes(T::IMG_BYTES));  // behind the fragment image in `ws`
-  auto k = mlp_bwd_fused_kernel<P, LAYOUT, DT, WLDS>;
-  hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, st, img, fs, ps, dout, dfd, slabs);
+  int rc = launch_with_lds(mlp_bwd_fused_kernel<P, LAYOUT, DT, WLDS>, dim3(blocks), dim3(256), lds, st, img, fs, ps, dout, dfd, slabs);
+  if (rc) return rc;
   hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(kSlabWg / 32), dim3(256), 0, st, (const float*)slabs, (int)blocks, dparams);
+  return HBR_OK;
 }
 
+// single pass, dW tiles shared by the four waves of a workgroup through an LDS fragment exchange
 template <int LAYOUT, int DT>
-static void launch_bwd(int precision, uint32_t ntiles, hipStream_t st, const char* img, FeatSrc fs, PeSrc ps, const float* dout,
-                       DFeatDst dfd, float* dparams) {
-#if HBR_BWD_SPLIT == 0
-  // single pass, dW tiles shared by the four waves of a workgroup through an LDS fragment exchange
-  if (precision == HBR_BF16) launch_bwd_fused<PBf16, LAYOUT, DT, true>(ntiles, st, img, fs, ps, dout, dfd, dparams);
-  else launch_bwd_fused<PF32, LAYOUT, DT, false>(ntiles, st, img, fs, ps, dout, dfd, dparams);
-#else
-  // earlier design kept for A/B builds (-DHBR_BWD_SPLIT=2|3): per-wave dW tiles, several launches by layer mask
-  constexpr int mSig = (1 << L1) | (1 << L2) | (1 << L3), mCol = (1 << C1) | (1 << C2) | (1 << C3);
-  if (precision == HBR_BF16) {
-#if HBR_BWD_SPLIT == 3
-    launch_bwd1<PBf16, LAYOUT, DT, 8, true, (1 << C3) | (1 << C2)>(ntiles, st, img, fs, ps, dout, dfd, dparams);
-    launch_bwd1<PBf16, LAYOUT, DT, 8, true, (1 << C1) | (1 << L3)>(ntiles, st, img, fs, ps, dout, dfd, dparams);
-    launch_bwd1<PBf16, LAYOUT, DT, 8, true, (1 << L2) | (1 << L1)>(ntiles, st, img, fs, ps, dout, dfd, dparams);
-#else
-    launch_bwd1<PBf16, LAYOUT, DT, 4, true, mSig>(ntiles, st, img, fs, ps, dout, dfd, dparams);
-    launch_bwd1<PBf16, LAYOUT, DT, 4, true, mCol>(ntiles, st, img, fs, ps, dout, dfd, dparams);
-#endif
-  } else {
-    launch_bwd1<PF32, LAYOUT, DT, 4, false, mSig>(ntiles, st, img, fs, ps, dout, dfd, dparams);
-    launch_bwd1<PF32, LAYOUT, DT, 4, false, mCol>(ntiles, st, img, fs, ps, dout, dfd, dparams);
-  }
-#endif
+static int launch_bwd(int precision, uint32_t ntiles, hipStream_t st, const char* img, FeatSrc fs, PeSrc ps, const float* dout,
+                      DFeatDst dfd, float* dparams) {
+  if (precision == HBR_BF16) return launch_bwd_fused<PBf16, LAYOUT, DT, true>(ntiles, st, img, fs, ps, dout, dfd, dparams);
+  return launch_bwd_fused<PF32, LAYOUT, DT, false>(ntiles, st, img, fs, ps, dout, dfd, dparams);
 }
 
 static int check_common(const void* feat, int layout, int64_t stride, int dt, const float* pe, int64_t N, int64_t group,
@@ -1327,13 +1062,14 @@ extern "C" int hbr_mlp_fwd(const void* feat, int layout, int64_t feat_stride, in
   char* img = (char*)ws;
   if (precision == HBR_BF16) {
     pack<PBf16>(params, img, st);
-    if (layout == HBR_LAYOUT_PLANAR) launch_fwd<PBf16, HBR_LAYOUT_PLANAR>(feat_dtype, blocks, st, img, fs, ps, out);
-    else launch_fwd<PBf16, HBR_LAYOUT_ROWS>(feat_dtype, blocks, st, img, fs, ps, out);
+    if (layout == HBR_LAYOUT_PLANAR) rc = launch_fwd<PBf16, HBR_LAYOUT_PLANAR>(feat_dtype, blocks, st, img, fs, ps, out);
+    else rc = launch_fwd<PBf16, HBR_LAYOUT_ROWS>(feat_dtype, blocks, st, img, fs, ps, out);
   } else {
     pack<PF32>(params, img, st);
-    if (layout == HBR_LAYOUT_PLANAR) launch_fwd<PF32, HBR_LAYOUT_PLANAR>(feat_dtype, blocks, st, img, fs, ps, out);
-    else launch_fwd<PF32, HBR_LAYOUT_ROWS>(feat_dtype, blocks, st, img, fs, ps, out);
+    if (layout == HBR_LAYOUT_PLANAR) rc = launch_fwd<PF32, HBR_LAYOUT_PLANAR>(feat_dtype, blocks, st, img, fs, ps, out);
+    else rc = launch_fwd<PF32, HBR_LAYOUT_ROWS>(feat_dtype, blocks, st, img, fs, ps, out);
   }
+  if (rc) return rc;
   HBR_RETURN_IF_LAUNCH_FAILED();
   return HBR_OK;
 }
@@ -1354,12 +1090,13 @@ extern "C" int hbr_mlp_bwd(const void* feat, int layout, int64_t feat_stride, in
   if (precision == HBR_BF16) pack<PBf16>(params, img, st);
   else pack<PF32>(params, img, st);
   if (layout == HBR_LAYOUT_PLANAR) {
-    if (feat_dtype == HBR_F32) launch_bwd<HBR_LAYOUT_PLANAR, HBR_F32>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams);
-    else launch_bwd<HBR_LAYOUT_PLANAR, HBR_BF16>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams);
+    if (feat_dtype == HBR_F32) rc = launch_bwd<HBR_LAYOUT_PLANAR, HBR_F32>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams);
+    else rc = launch_bwd<HBR_LAYOUT_PLANAR, HBR_BF16>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams);
   } else {
-    if (feat_dtype == HBR_F32) launch_bwd<HBR_LAYOUT_ROWS, HBR_F32>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams);
-    else launch_bwd<HBR_LAYOUT_ROWS, HBR_BF16>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams);
+    if (feat_dtype == HBR_F32) rc = launch_bwd<HBR_LAYOUT_ROWS, HBR_F32>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams);
+    else rc = launch_bwd<HBR_LAYOUT_ROWS, HBR_BF16>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams);
   }
+  if (rc) return rc;
   HBR_RETURN_IF_LAUNCH_FAILED();
   return HBR_OK;
 }

@@ -12,13 +12,34 @@ from typing import Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, PLANAR, ROWS, check, lib, require_gpu
+from ._lib import BF16, F32, PLANAR, ROWS, HbrError, check, lib, require_gpu
 
 _ws_cache = {}
 
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+def _elem_dtype(t: torch.Tensor, what: str) -> int:
+    """F32 / BF16 code of a feature or feature-gradient buffer.  Anything else (fp16 is what the reference's
+    torch.cuda.amp.autocast() hands out, fp64 what a careless .double() does) is refused rather than reinterpreted."""
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise HbrError(f"{what} must be float32 or bfloat16, got {t.dtype} (cast it explicitly)")
+
+
+def _workspace(kind, nbytes: int, device) -> torch.Tensor:
+    """Scratch buffers are keyed by (kind, device, STREAM): kernels of one stream run in order, so a buffer may be
+    reused by the next call on that stream, while two streams never share one.  Grows, never shrinks."""
+    key = (kind, device, _stream())
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes + 64, dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -32,12 +53,7 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 
 
 def _mlp_ws(precision: int, device) -> torch.Tensor:
-    key = (precision, device)
-    ws = _ws_cache.get(key)
-    if ws is None:
-        ws = torch.empty(lib().hbr_mlp_workspace_bytes(precision) + 64, dtype=torch.uint8, device=device)
-        _ws_cache[key] = ws
-    return ws
+    return _workspace(("mlp", precision), lib().hbr_mlp_workspace_bytes(precision), device)
 
 
 @dataclass(frozen=True)
@@ -100,8 +116,11 @@ def hash_encode_fwd(geom: HashGeom, tables: torch.Tensor, x: Optional[torch.Tens
 
 
 def hash_encode_bwd(geom: HashGeom, dy: torch.Tensor, dtables: torch.Tensor, x: Optional[torch.Tensor] = None, rays=None,
-                    layout: int = ROWS, algo: int = 0):
-    """Accumulates into dtables [L,T,F] fp32."""
+                    layout: int = ROWS, algo: int = 0, dy_absmax: Optional[torch.Tensor] = None, deterministic: bool = True):
+    """Accumulates into dtables [L,T,F] fp32.  algo 0 = auto (LDS-slice fixed-point kernel from 65536 points), 1 = global
+    float atomics, 2 = LDS-slice kernel.  `deterministic` (algo 2): reduce the chunk partials in a fixed order (full
+    workspace) instead of with float atomics.  `dy_absmax` [L] fp32 on the device: per-level max |dy| if the caller
+    already has it."""
     require_gpu(dy)
     if x is not None:
         x = _f32c(x)
@@ -112,15 +131,20 @@ def hash_encode_bwd(geom: HashGeom, dy: torch.Tensor, dtables: torch.Tensor, x: 
         R, S = o.shape[0], t.shape[0]
     if not dy.is_contiguous():
         dy = dy.contiguous()
-    dtype = F32 if dy.dtype == torch.float32 else BF16
+    dtype = _elem_dtype(dy, "dy")
+    if dtables.dtype != torch.float32 or not dtables.is_contiguous():
+        raise HbrError("dtables must be a contiguous float32 [L,T,F] buffer")
     stride = dy.shape[-1] if layout == ROWS else 0
     if R * S == 0:
         return dtables
     sc, mu = geom.c_args()
-    nws = 0 if os.environ.get("HBR_K2_NOCACHE") else lib().hbr_hash_bwd_workspace_bytes(R * S, geom.L, geom.T, geom.F, algo)
-    ws = torch.empty(nws, dtype=torch.uint8, device=dy.device) if nws else None
-    check(lib().hbr_hash_encode_bwd(_ptr(x), _ptr(o), _ptr(d), _ptr(t), R, S, dy.data_ptr(), layout, stride, dtype, sc, mu,
-                                    geom.sigma, geom.L, geom.T, geom.F, dtables.data_ptr(), algo, _ptr(ws), nws, _stream()),
+    size_fn = lib().hbr_hash_bwd_workspace_bytes if deterministic else lib().hbr_hash_bwd_workspace_bytes_min
+    nws = size_fn(R * S, geom.L, geom.T, geom.F, algo)
+    ws = _workspace("hash_bwd", nws, dy.device) if nws else None
+    if dy_absmax is not None:
+        dy_absmax = _f32c(dy_absmax)
+    check(lib().hbr_hash_encode_bwd(_ptr(x), _ptr(o), _ptr(d), _ptr(t), R, S, dy.data_ptr(), layout, stride, dtype, _ptr(dy_absmax),
+                                    sc, mu, geom.sigma, geom.L, geom.T, geom.F, dtables.data_ptr(), algo, _ptr(ws), nws, _stream()),
           "hbr_hash_encode_bwd")
     return dtables
 
@@ -137,7 +161,7 @@ def dir_encode(x: torch.Tensor, num_freq: int) -> torch.Tensor:
 
 
 def _feat_desc(feat: torch.Tensor, layout: int):
-    dtype = F32 if feat.dtype == torch.float32 else BF16
+    dtype = _elem_dtype(feat, "feat")
     if layout == PLANAR:
         N = feat.shape[1]
         stride = 0
@@ -162,7 +186,9 @@ def mlp_fwd(feat: torch.Tensor, layout: int, viewdirs_enc: torch.Tensor, group: 
 def mlp_bwd(feat: torch.Tensor, layout: int, viewdirs_enc: torch.Tensor, group: int, params: torch.Tensor, precision: int,
             dout: torch.Tensor, dparams: torch.Tensor, need_dfeat: bool = True):
     N, stride, dtype = _feat_desc(feat, layout)
-    dfeat = torch.empty_like(feat) if need_dfeat else None
+    # d feat takes feat's layout INCLUDING its row stride (the kernel addresses both with feat_stride): a strided rows
+    # view such as y[:, :32] of an [N,36] buffer gets a gradient buffer with the same 36-element pitch
+    dfeat = torch.empty_strided(feat.shape, feat.stride(), dtype=feat.dtype, device=feat.device) if need_dfeat else None
     ws = _mlp_ws(precision, feat.device)
     dout = _f32c(dout)
     if N == 0:
@@ -201,8 +227,12 @@ def mse2_loss(Cr: torch.Tensor, gt: torch.Tensor, gscale: float = 1.0, want_grad
     Cr, gt = _f32c(Cr), _f32c(gt)
     loss = torch.zeros((), dtype=torch.float32, device=Cr.device)
     dCr = torch.empty_like(Cr) if want_grad else None
-    check(lib().hbr_mse2_loss_fwd_bwd(Cr.data_ptr(), gt.data_ptr(), Cr.shape[0], gscale, loss.data_ptr(), _ptr(dCr), _stream()),
-          "hbr_mse2_loss_fwd_bwd")
+    key = ("mse2", Cr.device, _stream())
+    ws = _ws_cache.get(key)
+    if ws is None:  # zeroed once: the kernel leaves its ticket word at zero
+        ws = _ws_cache[key] = torch.zeros(lib().hbr_mse2_workspace_bytes(), dtype=torch.uint8, device=Cr.device)
+    check(lib().hbr_mse2_loss_fwd_bwd(Cr.data_ptr(), gt.data_ptr(), Cr.shape[0], gscale, loss.data_ptr(), _ptr(dCr), ws.data_ptr(),
+                                      _stream()), "hbr_mse2_loss_fwd_bwd")
     return loss, dCr
 
 
@@ -259,16 +289,18 @@ class MlpFn(torch.autograd.Function):
         if feat_c.stride(-1) != 1 or feat_c.stride(0) % 4 or feat_c.data_ptr() % 16:
             feat_c = feat_c.contiguous()
         pe = _f32c(viewdirs_enc.detach())
-        ctx.save_for_backward(feat_c, pe)
-        ctx.flat, ctx.group, ctx.precision, ctx.splits = flat, group, precision, splits
+        # `flat` (the live parameter block) is saved too: the backward recomputes activations from it, and autograd's
+        # version check then catches an optimiser step taken between forward and backward
+        ctx.save_for_backward(feat_c, pe, flat)
+        ctx.group, ctx.precision, ctx.splits = group, precision, splits
         ctx.need_dfeat = feat.requires_grad
         return mlp_fwd(feat_c, ROWS, pe, group, flat, precision)
 
     @staticmethod
     def backward(ctx, dout):
-        feat, pe = ctx.saved_tensors
-        dflat = torch.zeros_like(ctx.flat)
-        dfeat = mlp_bwd(feat, ROWS, pe, ctx.group, ctx.flat, ctx.precision, dout, dflat, need_dfeat=ctx.need_dfeat)
+        feat, pe, flat = ctx.saved_tensors
+        dflat = torch.zeros_like(flat)
+        dfeat = mlp_bwd(feat, ROWS, pe, ctx.group, flat, ctx.precision, dout, dflat, need_dfeat=ctx.need_dfeat)
         grads = tuple(dflat[a:b].view(shape) for (a, b, shape) in ctx.splits)
         return (dfeat, None, None, None, None, None) + grads
 
@@ -319,21 +351,21 @@ class RenderFn(torch.autograd.Function):
         feat = hash_encode_fwd(geom, stacked, x=x, rays=rays, layout=PLANAR, dtype=feat_dtype)
         out = mlp_fwd(feat, PLANAR, pe, S, flat, precision)
         Cr, wts = composite_fwd(t, out.data_ptr(), 4, out.data_ptr() + 12, 4, dn, R, S)
-        ctx.save_for_backward(o, d, t, pe, feat, out)
+        ctx.save_for_backward(o, d, t, pe, feat, out, flat)  # flat: see MlpFn
         ctx.x = x
-        ctx.dn, ctx.geom, ctx.flat, ctx.precision, ctx.splits, ctx.n_tab = dn, geom, flat, precision, splits, n_tab
+        ctx.dn, ctx.geom, ctx.precision, ctx.splits, ctx.n_tab = dn, geom, precision, splits, n_tab
         ctx.mark_non_differentiable(wts, out)
         return Cr, wts, out
 
     @staticmethod
     def backward(ctx, dCr, _dw, _dout):
-        o, d, t, pe, feat, out = ctx.saved_tensors
+        o, d, t, pe, feat, out, flat = ctx.saved_tensors
         g = ctx.geom
         R, S = o.shape[0], t.shape[-1]
         d_out = torch.empty_like(out)
         composite_bwd(t, out.data_ptr(), 4, out.data_ptr() + 12, 4, ctx.dn, R, S, _f32c(dCr), d_out.data_ptr(), d_out.data_ptr() + 12)
-        dflat = torch.zeros_like(ctx.flat)
-        dfeat = mlp_bwd(feat, PLANAR, pe, S, ctx.flat, ctx.precision, d_out, dflat)
+        dflat = torch.zeros_like(flat)
+        dfeat = mlp_bwd(feat, PLANAR, pe, S, flat, ctx.precision, d_out, dflat)
         dtab = torch.zeros((g.L, g.T, g.F), dtype=torch.float32, device=o.device)
         rays = None if ctx.x is not None else (o, d, t)
         hash_encode_bwd(g, dfeat, dtab, x=ctx.x, rays=rays, layout=PLANAR)

@@ -39,7 +39,7 @@ class HashNeRFTrainer:
     def __init__(self, encoder: HashEncoder, mlp: MLP_3D, near: float = 2.0, far: float = 6.0, num_samples: int = 128,
                  total_steps: int = 100000, lr_embed: float = 0.05, lr_mlp: float = 0.005, eta_min: float = 1e-4,
                  weight_decay_mlp: float = 0.01, precision: int = BF16, feat_dtype: Optional[int] = None, num_freq: int = 4,
-                 process_group=None, scatter_algo: int = 0, overlap_comm: bool = True):
+                 process_group=None, scatter_algo: int = 0, overlap_comm: bool = True, split_scatter: Optional[bool] = None):
         self.enc, self.mlp = encoder, mlp
         self.near, self.far, self.S = float(near), float(far), int(num_samples)
         self.total_steps = int(total_steps)
@@ -57,8 +57,11 @@ class HashNeRFTrainer:
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
-        self.tables = encoder.stacked_tables()
-        self.flat, self.splits = mlp.flat_params()
+        # The scatter kernel runs as two half-level launches so that each half's all-reduce overlaps the other half's
+        # kernel.  Default: only when there is something to overlap (world > 1); tests force it on a single GPU, where
+        # the staged reduce is a no-op and the result must equal the single launch.
+        self.split_scatter = (self.world > 1 and overlap_comm) if split_scatter is None else bool(split_scatter)
+        self._bind_parameters()
         dev = self.tables.device
         self.geom = encoder.geometry()
         self.n_tab = self.tables.numel()
@@ -74,6 +77,15 @@ class HashNeRFTrainer:
         self.timers = None  # optional dict name -> list[(start_event, end_event)], filled when set by bench.py
 
     # ---- helpers ------------------------------------------------------------------------------
+    def _bind_parameters(self):
+        """(Re-)fetch the stacked table buffer and the flat MLP block from the modules.  Both calls are cheap pointer
+        checks that re-establish the aliasing if a caller replaced parameter storages (load_state_dict into fresh
+        tensors, .to() round trips), so the trainer never trains a stale copy."""
+        self.tables = self.enc.stacked_tables()
+        self.flat, self.splits = self.mlp.flat_params()
+        if getattr(self, "grad", None) is not None and self.grad.device != self.tables.device:
+            raise RuntimeError("the modules were moved to another device after the trainer was built; build a new trainer")
+
     def _timed(self, name, fn):
         if self.timers is None:
             return fn()
@@ -90,6 +102,7 @@ class HashNeRFTrainer:
     # ---- one optimisation step ------------------------------------------------------------------
     def step(self, rays_o, rays_d, dir_norm, gt, t: Optional[torch.Tensor] = None):
         """rays_o/rays_d [R,3], dir_norm [R,1] or [R], gt [R,3], all resident on the GPU."""
+        self._bind_parameters()
         S, g = self.S, self.geom
         R = rays_o.shape[0]
         if t is None:
@@ -107,11 +120,12 @@ class HashNeRFTrainer:
         ops.composite_bwd(t, out.data_ptr(), 4, out.data_ptr() + 12, 4, dn, R, S, dCr, d_out.data_ptr(), d_out.data_ptr() + 12)
         self.grad.zero_()
         dfeat = self._timed("mlp_bwd", lambda: ops.mlp_bwd(feat, PLANAR, pe, S, self.flat, self.precision, d_out, self.g_mlp))
-        if self.world > 1 and self.overlap_comm and g.L >= 2:
+        if self.split_scatter and g.L >= 2:
             # The step's one all-reduce, issued in three pieces that partition the flat gradient buffer: the MLP block
             # (final after K4), then the upper half of the levels while the lower half's scatter is still running.
             # Only the last piece (4 MiB at L = 16) is exposed.  Planar [L,N,2] dfeat and [L,T,F] grads make a level
-            # range a contiguous slice, so the same kernel runs on each half.
+            # range a contiguous slice, so the same kernel runs on each half (bit-identical to the single launch:
+            # tests/test_gpu_shipped_paths.py).  With world == 1 the reduce calls are no-ops.
             red = StagedAllReduce(self.world, self.pg)
             nt, half = self.n_tab, g.L // 2
             cut = half * g.T * g.F

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HBR_VERSION 100 /* 0.1.0 */
+#define HBR_VERSION 200 /* 0.2.0 */
 
 enum {
   HBR_OK = 0,
@@ -70,17 +70,29 @@ int hbr_hash_encode_fwd(const float* x, const float* rays_o, const float* rays_d
 /* ---- K2: gradient scatter-add into the tables ------------------------------------------------
  * Replaces autograd of the above (16x aten::embedding_dense_backward + mul/sum backward).
  *   dy       same layout/dtype conventions as y
+ *   dy_absmax optional DEVICE [L] fp32: max |dy| per level (e.g. produced by the kernel that wrote dy);
+ *            NULL => computed here by one extra pass over dy.  Must be >= the true maximum.
  *   dtables  [L,T,F] fp32, ACCUMULATED INTO (caller zeroes it when a fresh gradient is wanted)
- *   algo     0 = auto, 1 = global float atomics, 2 = LDS-partitioned fp64 accumulate, atomic flush
- *   ws       optional 16-byte-aligned scratch of hbr_hash_bwd_workspace_bytes() bytes (the LDS-slice algorithm
- *            caches the normalised coordinates there once per call); NULL / too small => recomputed per visit
+ *   algo     1 = one global float atomic per corner-feature (no workspace; any T; order-dependent rounding)
+ *            2 = LDS-partitioned accumulation in 64-bit fixed point (scale 2^k per level from max |dy|, so every
+ *                contribution is rounded once and the integer sums are order-independent): needs `ws`, T <= 2^28.
+ *                With the full workspace the chunk partials are reduced in a fixed order and the result of a launch
+ *                is bitwise reproducible; with only the first hbr_hash_bwd_workspace_bytes_min() bytes they are
+ *                added with float atomics (same values up to the order of <= chunks fp32 additions per entry).
+ *            0 = auto: 2 when N >= 65536, T <= 2^28 and the workspace suffices, else 1
+ *   ws       16-byte-aligned scratch of hbr_hash_bwd_workspace_bytes() bytes (normalised coordinates, per-level
+ *            maxima, per-chunk partial tables); contents are dead after the call
+ *   errors   algo 2 without enough workspace -> HBR_EWORKSPACE; algo 2 with T > 2^28 -> HBR_EUNSUPPORTED
  */
 int hbr_hash_encode_bwd(const float* x, const float* rays_o, const float* rays_d, const float* t,
                         int64_t R, int64_t S, const void* dy, int layout, int64_t dy_stride,
-                        int dy_dtype, const float* scales_host, const float* mu_host, float sigma,
-                        int L, int64_t T, int F, float* dtables, int algo, void* ws,
-                        int64_t ws_bytes, void* stream);
+                        int dy_dtype, const float* dy_absmax, const float* scales_host,
+                        const float* mu_host, float sigma, int L, int64_t T, int F, float* dtables,
+                        int algo, void* ws, int64_t ws_bytes, void* stream);
+/* full workspace of algo 2 for this shape (0 when `algo`/N/T select the global-atomics kernel) */
 int64_t hbr_hash_bwd_workspace_bytes(int64_t N, int L, int64_t T, int F, int algo);
+/* the part of it algo 2 cannot run without (coordinates + maxima, 12 B per point) */
+int64_t hbr_hash_bwd_workspace_bytes_min(int64_t N, int L, int64_t T, int F, int algo);
 
 /* ---- K5: alpha compositing along rays ---------------------------------------------------------
  * Replaces calc_color, helper.py:53-107 (non-SDF branch).
@@ -136,9 +148,13 @@ int hbr_mlp_bwd(const void* feat, int layout, int64_t feat_stride, int feat_dtyp
 
 /* ---- a11: loss + its gradient -----------------------------------------------------------------
  * train_hash2.py:177,221 with hierarchical off: loss = 2*mean((Cr-gt)^2); dCr = 4*(Cr-gt)/(3R) * gscale.
- * loss_out: one fp32, accumulated into (caller zeroes).  */
+ * loss_out: one fp32, accumulated into (caller zeroes).
+ * ws: optional scratch of hbr_mse2_workspace_bytes() bytes whose LAST 4 bytes are zero on first use (the kernel
+ *     leaves them zero): block sums are then added in a fixed order and the loss is bitwise reproducible.
+ *     NULL => one float atomic per block.  */
+int64_t hbr_mse2_workspace_bytes(void);
 int hbr_mse2_loss_fwd_bwd(const float* Cr, const float* gt, int64_t R, float gscale, float* loss_out,
-                          float* dCr, void* stream);
+                          float* dCr, void* ws, void* stream);
 
 /* ---- a12: dense Adam / AdamW over a flat fp32 buffer -----------------------------------------
  * torch.optim.Adam / AdamW single-tensor semantics (train_hash2.py:141-142): decoupled weight decay

@@ -1,0 +1,280 @@
+"""GPU (-m gpu): DIRECT oracle parity for the kernel instantiations the benchmark times, plus the
+properties the round-2 scatter kernel adds.
+
+* K2 as shipped: N >= 65536 points, planar bf16 dy, LDS-slice kernel with its workspace (fixed-point accumulation,
+  slab flush) against oracle/ref_cpu.hash_encode_backward on the same bf16-rounded dy - rtol 1e-4 and the exact set of
+  touched rows (reference hash_encoding.py:146-170, autograd's embedding_dense_backward).
+* K2 determinism: integer accumulation + fixed-order reduce => two launches agree bit for bit.
+* K2 over level sub-ranges exactly as the multi-GPU trainer launches it (trainer.py world > 1 branch) == one launch.
+* K4 as shipped: planar bf16 features in, bf16 MFMA, bf16 feature gradient out, against the oracle under torch's bf16
+  autocast on the same bf16-rounded features (reference test_hash.py:52-72 under train_hash2.py:218).
+"""
+import numpy as np
+import pytest
+import torch
+
+import ref_cpu
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from hbr_amd import ops as o
+    from hbr_amd import _lib as L
+    assert L.lib().hbr_device_ok() == 1
+    return o
+
+
+def _scene(ops, R, S, T, seed):
+    o, d, _, _ = ref_cpu.synthetic_rays(R, seed=seed)
+    mn, mx, sig = ref_cpu.bbox_mu_sigma(o, d)
+    sc = ref_cpu.level_scales(16, 2048.0, 16)
+    geom = ops.HashGeom(tuple(float(v) for v in sc), tuple(float(v) for v in mn), float(sig), T, 2)
+    t = ref_cpu.strat_jitter_to_t(2.0, 6.0, S, torch.rand(S, generator=torch.Generator().manual_seed(seed + 1)))
+    return o, d, t, mn, sig, sc, geom
+
+
+def test_k2_shipped_instantiation_vs_oracle(ops):
+    """131 072 points (1024 rays x 128 samples), T = 2^16, planar bf16 dy with a wide dynamic range (|dy| spans six
+    decades, like gradients behind and in front of a surface) - the exact kernel bench.py times."""
+    from hbr_amd._lib import PLANAR, lib
+    R, S, L, T = 1024, 128, 16, 2 ** 16
+    N = R * S
+    o, d, t, mn, sig, sc, geom = _scene(ops, R, S, T, seed=41)
+    assert lib().hbr_hash_bwd_workspace_bytes(N, L, T, 2, 0) > 0  # auto picks the LDS-slice kernel at this size
+    rng = np.random.default_rng(42)
+    mag = 10.0 ** rng.uniform(-6, 0, (N, 1))
+    dy32 = (rng.standard_normal((N, L * 2)) * mag).astype(np.float32)
+    dy_bf = torch.from_numpy(dy32).bfloat16()                                # [N,32] bf16
+    dy_planar = dy_bf.reshape(N, L, 2).permute(1, 0, 2).contiguous().to(DEV)  # [L,N,2]
+    pts = ref_cpu.sample_points(o, d, t).reshape(-1, 3)
+    ref = ref_cpu.hash_encode_backward(pts, dy_bf.float(), sc, mn, sig, T).numpy()
+
+    got = torch.zeros((L, T, 2), device=DEV)
+    ops.hash_encode_bwd(geom, dy_planar, got, rays=(o.to(DEV), d.to(DEV), t.to(DEV)), layout=PLANAR, algo=0)
+    g = got.cpu().numpy()
+    # per-contribution rounding to the 2^-44-of-max quantum and fp32 rounding of <= 1 chunk partial: rtol 1e-4
+    assert np.allclose(g, ref, rtol=1e-4, atol=1e-6 * np.abs(ref).max())
+    # index parity: no row outside the reference's touched set, and every row the reference gives more than the
+    # fixed-point quantum (2^-43 of the level's largest |dy| at this N; |dy| spans six decades here and a trilinear
+    # weight can be 1e-7, so a few thousand-billionth-sized entries legitimately round to zero)
+    assert not np.any((g != 0) & (ref == 0))
+    assert np.all((g != 0) | (np.abs(ref) < 1e-10 * np.abs(ref).max()))
+    # the float-atomic flush (minimal workspace) and the global-atomics kernel agree with it
+    for kw in (dict(algo=2, deterministic=False), dict(algo=1)):
+        alt = torch.zeros((L, T, 2), device=DEV)
+        ops.hash_encode_bwd(geom, dy_planar, alt, rays=(o.to(DEV), d.to(DEV), t.to(DEV)), layout=PLANAR, **kw)
+        assert np.allclose(alt.cpu().numpy(), ref, rtol=1e-4, atol=1e-6 * np.abs(ref).max()), kw
+    # a caller-supplied per-level maximum (any upper bound) gives the same bits as the internal pass when equal
+    amax = dy_planar.float().abs().amax(dim=(1, 2))
+    again = torch.zeros((L, T, 2), device=DEV)
+    ops.hash_encode_bwd(geom, dy_planar, again, rays=(o.to(DEV), d.to(DEV), t.to(DEV)), layout=PLANAR, algo=2, dy_absmax=amax)
+    assert torch.equal(again, got)
+
+
+def test_k2_is_bitwise_reproducible_and_accumulates(ops):
+    from hbr_amd._lib import PLANAR
+    R, S, L, T = 2048, 128, 16, 2 ** 16
+    o, d, t, mn, sig, sc, geom = _scene(ops, R, S, T, seed=43)
+    rays = (o.to(DEV), d.to(DEV), t.to(DEV))
+    gen = torch.Generator(device=DEV).manual_seed(44)
+    dy = (torch.randn((L, R * S, 2), device=DEV, generator=gen) * 1e-3).bfloat16()
+    runs = []
+    for _ in range(3):
+        g = torch.zeros((L, T, 2), device=DEV)
+        ops.hash_encode_bwd(geom, dy, g, rays=rays, layout=PLANAR, algo=2)
+        runs.append(g)
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+    # ACCUMULATES into dtables: a second call on top of the first doubles every entry exactly (x + x is exact)
+    ops.hash_encode_bwd(geom, dy, runs[0], rays=rays, layout=PLANAR, algo=2)
+    assert torch.equal(runs[0], 2 * runs[1])
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_k2_level_halves_equal_single_launch(ops, algo, dt):
+    """The multi-GPU trainer scatters levels [L/2, L) and then [0, L/2) with sub-geometries on slices of the planar
+    gradient, so that each half's all-reduce overlaps the other half's kernel (trainer.py).  Same result as one launch:
+    bit-identical for the fixed-point kernel, within atomic-ordering noise for the global-atomics one."""
+    from hbr_amd._lib import PLANAR
+    R, S, L, T = 600, 128, 16, 2 ** 16
+    o, d, t, mn, sig, sc, geom = _scene(ops, R, S, T, seed=45)
+    rays = (o.to(DEV), d.to(DEV), t.to(DEV))
+    gen = torch.Generator(device=DEV).manual_seed(46)
+    dy = torch.randn((L, R * S, 2), device=DEV, generator=gen).to(dt)
+    one = torch.zeros((L, T, 2), device=DEV)
+    ops.hash_encode_bwd(geom, dy, one, rays=rays, layout=PLANAR, algo=algo)
+    two = torch.zeros((L, T, 2), device=DEV)
+    half = L // 2
+    for lo, hi in ((half, L), (0, half)):
+        sub = ops.HashGeom(geom.scales[lo:hi], geom.mu, geom.sigma, geom.T, geom.F)
+        ops.hash_encode_bwd(sub, dy[lo:hi], two[lo:hi], rays=rays, layout=PLANAR, algo=algo)
+    if algo == 2:
+        assert torch.equal(one, two)
+    else:
+        assert torch.allclose(one, two, rtol=1e-4, atol=1e-5 * float(one.abs().max()))
+
+
+def test_k2_zero_and_nonfinite_gradients(ops):
+    """A level whose gradient is all zero contributes nothing; a NaN or inf in a level's dy poisons that level (as
+    float accumulation would) and leaves the others exact."""
+    from hbr_amd._lib import PLANAR
+    R, S, L, T = 512, 128, 16, 2 ** 14
+    o, d, t, mn, sig, sc, geom = _scene(ops, R, S, T, seed=47)
+    rays = (o.to(DEV), d.to(DEV), t.to(DEV))
+    gen = torch.Generator(device=DEV).manual_seed(48)
+    dy = torch.randn((L, R * S, 2), device=DEV, generator=gen)
+    clean = torch.zeros((L, T, 2), device=DEV)
+    ops.hash_encode_bwd(geom, dy, clean, rays=rays, layout=PLANAR, algo=2)
+    dy2 = dy.clone()
+    dy2[3] = 0.0
+    dy2[5, 1234, 1] = float("nan")
+    dy2[9, 77, 0] = float("inf")
+    g = torch.zeros((L, T, 2), device=DEV)
+    ops.hash_encode_bwd(geom, dy2, g, rays=rays, layout=PLANAR, algo=2)
+    assert float(g[3].abs().max()) == 0.0
+    assert bool(torch.isnan(g[5]).any()) and bool(torch.isnan(g[9]).any())
+    keep = [l for l in range(L) if l not in (3, 5, 9)]
+    assert torch.equal(g[keep], clean[keep])
+
+
+def test_k2_refuses_what_it_cannot_do(ops):
+    from hbr_amd._lib import HbrError, PLANAR
+    R, S, L, T = 512, 128, 16, 2 ** 14
+    o, d, t, mn, sig, sc, geom = _scene(ops, R, S, T, seed=49)
+    rays = (o.to(DEV), d.to(DEV), t.to(DEV))
+    g = torch.zeros((L, T, 2), device=DEV)
+    with pytest.raises(HbrError):  # fp16 is what torch.cuda.amp.autocast() produces: refuse, do not reinterpret as bf16
+        ops.hash_encode_bwd(geom, torch.zeros((L, R * S, 2), device=DEV, dtype=torch.float16), g, rays=rays, layout=PLANAR)
+    with pytest.raises(HbrError):
+        ops.mlp_fwd(torch.zeros((64, 32), device=DEV, dtype=torch.float64), 0, torch.zeros((64, 24), device=DEV), 1,
+                    torch.zeros(14227, device=DEV), 0)
+    from hbr_amd._lib import lib
+    big = ops.HashGeom(geom.scales, geom.mu, geom.sigma, 2 ** 29, 2)  # row offsets would overflow 32 bits in the LDS kernel
+    assert lib().hbr_hash_bwd_workspace_bytes(R * S, L, big.T, 2, 2) == 0
+
+    def raw_call(gm, ws_ptr, ws_bytes):
+        sc_, mu_ = gm.c_args()
+        return lib().hbr_hash_encode_bwd(None, rays[0].data_ptr(), rays[1].data_ptr(), rays[2].data_ptr(), R, S, g.data_ptr(), PLANAR, 0,
+                                         0, None, sc_, mu_, gm.sigma, L, gm.T, 2, g.data_ptr(), 2, ws_ptr, ws_bytes, None)
+
+    scratch = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
+    assert raw_call(big, scratch.data_ptr(), scratch.numel()) == -2  # HBR_EUNSUPPORTED: algo 2 with T > 2^28
+    assert raw_call(geom, None, 0) == -4                              # HBR_EWORKSPACE: algo 2 without its workspace
+    assert raw_call(geom, scratch.data_ptr(), 1024) == -4
+    torch.cuda.synchronize()
+
+
+def test_k4_shipped_instantiation_vs_oracle_autocast(ops):
+    """G5's inputs with the features pre-rounded to bf16, through `layout=PLANAR, feat dtype=BF16, precision=BF16`
+    (what the fused trainer runs), against the oracle under torch's bf16 autocast on the same rounded features.
+    Calibration as in test_mlp_forward_backward_vs_reference_golden: the HIP kernel may be at most 1.5x as far from
+    the fp32 golden values as torch's own bf16 autocast is."""
+    from hbr_amd._lib import BF16, PLANAR
+    g = load_golden("g5_mlp.npz")
+    keys = [f"{s}.{i}.{k}" for s in ("sig_model", "col_model") for i in (0, 2, 4) for k in ("weight", "bias")]
+    flat = np.concatenate([g["p." + k].reshape(-1) for k in keys]).astype(np.float32)
+    N = g["feat"].shape[0]
+    feat_bf = torch.from_numpy(g["feat"]).bfloat16()
+    dirs = torch.from_numpy(g["dirs"])
+    dout = torch.from_numpy(g["dout"])
+    # oracle: bf16 autocast on the rounded features
+    prm = {k: torch.from_numpy(g["p." + k]).clone().requires_grad_(True) for k in keys}
+    f_c = feat_bf.float().clone().requires_grad_(True)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        o_c = ref_cpu.mlp_forward(f_c, ref_cpu.dir_encode(dirs, 4), prm)
+    o_c.float().backward(dout)
+    # the same thing in exact fp32 on the rounded features: the yardstick both are measured against
+    prm32 = {k: torch.from_numpy(g["p." + k]).clone().requires_grad_(True) for k in keys}
+    f32 = feat_bf.float().clone().requires_grad_(True)
+    o32 = ref_cpu.mlp_forward(f32, ref_cpu.dir_encode(dirs, 4), prm32)
+    o32.backward(dout)
+
+    feat_planar = feat_bf.reshape(N, 16, 2).permute(1, 0, 2).contiguous().to(DEV)
+    pe = ops.dir_encode(dirs.to(DEV), 4)
+    P = torch.from_numpy(flat).to(DEV)
+    out = ops.mlp_fwd(feat_planar, PLANAR, pe, 1, P, BF16)
+    dP = torch.zeros_like(P)
+    dfeat = ops.mlp_bwd(feat_planar, PLANAR, pe, 1, P, BF16, dout.to(DEV), dP)
+    assert dfeat.dtype == torch.bfloat16 and tuple(dfeat.shape) == (16, N, 2)
+
+    rel = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+    def check(got, exact, autocast, what):
+        r_hip, r_torch = rel(got, exact), rel(autocast, exact)
+        assert r_hip <= max(1.5 * r_torch, 5e-3) and r_hip < 0.1, (what, r_hip, r_torch)
+
+    check(out.cpu().numpy(), o32.detach().numpy(), o_c.detach().float().numpy(), "out")
+    check(dfeat.float().permute(1, 0, 2).reshape(N, 32).cpu().numpy(), f32.grad.numpy(), f_c.grad.numpy(), "dfeat")
+    dPn, off = dP.cpu().numpy(), 0
+    for k in keys:
+        n = prm32[k].grad.numel()
+        check(dPn[off:off + n].reshape(prm32[k].grad.shape), prm32[k].grad.numpy(), prm[k].grad.numpy(), k)
+        off += n
+
+
+def test_mlp_strided_rows_view_forward_and_backward(ops):
+    """feat = y[:, :32] of an [N,36] buffer (the encoder's E aux columns): kept as a strided view when 16-byte aligned.
+    The feature gradient must come back with the same pitch - no write past an [N,32] allocation."""
+    rng = np.random.default_rng(51)
+    N = 300
+    wide = torch.from_numpy(rng.standard_normal((N, 36)).astype(np.float32)).to(DEV)
+    view = wide[:, :32]
+    dense = view.contiguous()
+    dirs = rng.standard_normal((N, 3)).astype(np.float32)
+    pe = ops.dir_encode(torch.from_numpy(dirs).to(DEV), 4)
+    P = torch.cat([v.reshape(-1) for v in ref_cpu.mlp_init(52).values()]).to(DEV)
+    assert torch.equal(ops.mlp_fwd(view, 0, pe, 1, P, 0), ops.mlp_fwd(dense, 0, pe, 1, P, 0))
+    dout = torch.from_numpy(rng.standard_normal((N, 4)).astype(np.float32)).to(DEV)
+    guard = torch.full((4096,), 7.0, device=DEV)  # allocated right after: an overrun would most likely land here
+    g1, g2 = torch.zeros_like(P), torch.zeros_like(P)
+    d_view = ops.mlp_bwd(view, 0, pe, 1, P, 0, dout, g1)
+    d_dense = ops.mlp_bwd(dense, 0, pe, 1, P, 0, dout, g2)
+    torch.cuda.synchronize()
+    assert d_view.stride(0) == 36 and tuple(d_view.shape) == (N, 32)
+    assert torch.equal(d_view, d_dense) and torch.equal(g1, g2)
+    assert bool((guard == 7.0).all())
+    # through autograd (MlpFn keeps the strided view)
+    from hbr_amd.test_hash import MLP_3D
+    mlp = MLP_3D(num_sig=2, num_col=2, L=16, F=2, d_view=24).to(DEV)
+    w = wide.clone().requires_grad_(True)
+    mlp(w[:, :32], pe).sum().backward()
+    assert w.grad is not None and float(w.grad[:, 32:].abs().max()) == 0.0 and float(w.grad[:, :32].abs().max()) > 0
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_trainer_split_scatter_branch_equals_single_launch(precision):
+    """HashNeRFTrainer's multi-GPU branch (two half-level K2 launches interleaved with the staged all-reduce,
+    trainer.py) forced on one GPU, where the reduce is a no-op: the gradient buffer, the updated parameters and the loss
+    must equal the single-launch step bit for bit (K2's integer accumulation makes that an equality, not a tolerance)."""
+    from hbr_amd import _lib, synthetic
+    from hbr_amd.trainer import HashNeRFTrainer, build_default_model
+    R, S = 1024, 128  # 131 072 points: the LDS-slice kernel on both paths
+    o, d, dn, gt = (a.to(DEV) for a in synthetic.scene_rays(R, seed=61))
+    mn, mx, sig = synthetic.ray_bbox(o, d)
+    prec = _lib.BF16 if precision == "bf16" else _lib.F32
+    t = ref_cpu.strat_jitter_to_t(2.0, 6.0, S, torch.rand(S, generator=torch.Generator().manual_seed(62))).to(DEV)
+    res = []
+    for split in (False, True):
+        enc, _, mlp = build_default_model(mn, sig, DEV, seed=7)
+        with torch.no_grad():  # gradients of useful size from step one
+            enc.stacked_tables().uniform_(-0.3, 0.3, generator=torch.Generator(device=DEV).manual_seed(63))
+        tr = HashNeRFTrainer(enc, mlp, num_samples=S, total_steps=100, precision=prec, split_scatter=split)
+        assert tr.split_scatter is split
+        first = float(tr.step(o, d, dn.reshape(-1), gt, t=t))
+        g1 = tr.grad.clone()
+        more = [float(tr.step(o, d, dn.reshape(-1), gt, t=t)) for _ in range(2)]
+        res.append((first, g1, more, tr.tables.clone()))
+    (l_a, g_a, m_a, t_a), (l_b, g_b, m_b, t_b) = res
+    nt = t_a.numel()
+    # step 1 starts from identical parameters: same loss, and the table block of the gradient is bit-identical (the MLP
+    # block still ends in <= 8 float atomics per bias address in mlp_dw_reduce_kernel, so it is compared to rounding)
+    assert l_a == l_b
+    assert torch.equal(g_a[:nt], g_b[:nt])
+    assert torch.allclose(g_a[nt:], g_b[nt:], rtol=1e-5, atol=1e-9)
+    # later steps inherit that rounding-level difference of the MLP parameters
+    assert np.allclose(m_a, m_b, rtol=1e-4)
+    assert torch.allclose(t_a, t_b, rtol=0, atol=2e-3)  # Adam steps are +-lr*sign(g) where |g| ~ 0

@@ -13,6 +13,8 @@ geom = ops.HashGeom(tuple(float(v) for v in sc), tuple(float(v) for v in mn), fl
 t = ref_cpu.strat_jitter_to_t(2.0, 6.0, S, torch.rand(S)).to(dev)
 o, d = o.to(dev), d.to(dev)
 dy = torch.rand((L, R * S, 2), device=dev)
+if os.environ.get("K2_BF16", "1") == "1":
+    dy = dy.bfloat16()
 dt = torch.zeros((L, T, 2), device=dev)
 which = sys.argv[1] if len(sys.argv) > 1 else "bwd"
 for _ in range(3):
