@@ -29,7 +29,7 @@ SIGNATURES = {
     "hbr_dir_encode": (_i, [_p, _l, _i, _i, _p, _p]),
     "hbr_mlp_workspace_bytes": (_l, [_i]),
     "hbr_mlp_fwd": (_i, [_p, _i, _l, _i, _p, _l, _l, _p, _i, _p, _p, _l, _p]),
-    "hbr_mlp_bwd": (_i, [_p, _i, _l, _i, _p, _l, _l, _p, _i, _p, _p, _p, _p, _l, _p]),
+    "hbr_mlp_bwd": (_i, [_p, _i, _l, _i, _p, _l, _l, _p, _i, _p, _p, _p, _p, _p, _l, _p]),
     "hbr_mse2_workspace_bytes": (_l, []),
     "hbr_mse2_loss_fwd_bwd": (_i, [_p, _p, _l, _f, _p, _p, _p, _p]),
     "hbr_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _l, _f, _p]),

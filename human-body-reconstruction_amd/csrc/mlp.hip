@@ -512,7 +512,9 @@ __device__ __host__ constexpr int db_base(int l) {
 struct DFeatDst {
   void* p;
   int64_t stride;
+  uint32_t* abs_part;  // optional [16 levels][kAbsWaves]: per-wave max |d feat| of each level (fp32 bit patterns), else nullptr
 };
+constexpr int kAbsWaves = 1024;  // kMaxBwdBlocks workgroups x 4 waves
 
 // ------------------------------------------------------------------------------------------------
 // weight-gradient flush: per-workgroup slabs + one reduce launch
@@ -536,8 +538,18 @@ __device__ __host__ constexpr int64_t slab_offset_bytes(int64_t img_bytes) { ret
 // "leader": the even wave / wave 0's lower half) also walks its siblings, in a fixed order, and the others return:
 // every parameter has exactly one writer and one summation order, i.e. the MLP gradient is bitwise reproducible.
 __global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(const float* __restrict__ slabs, int nblocks,
-                                                            float* __restrict__ dparams) {
+                                                            float* __restrict__ dparams, const uint32_t* __restrict__ abs_part,
+                                                            float* __restrict__ absmax_out) {
   __shared__ float part[8][32];
+  if (blockIdx.x == kSlabWg / 32) {  // the extra block: per-level max |d feat| over the waves' partials -> absmax_out[16]
+    const int level = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    uint32_t m = 0;
+    for (int w = sub; w < nblocks * 4; w += 16) m = max(m, abs_part[(size_t)level * kAbsWaves + w]);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+    if (sub == 0) absmax_out[level] = __uint_as_float(m);
+    return;
+  }
   const int el = threadIdx.x & 31, p = threadIdx.x >> 5;
   const int e = blockIdx.x * 32 + el;  // (wave, register, lane) of the slab layout; kSlabWg is a multiple of 32
   // where this slab entry belongs in the flat parameter block (-1: a padding row/column of its tile, or a sibling
@@ -818,6 +830,11 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
   for (int l = 0; l < NLAYER; ++l)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[l][q] = 0.f;
+  // running max |d feat| (as stored, fp32 bit patterns) of the lane's 8 levels 4g + 2h + {0,1}: the scatter kernel's
+  // fixed-point scale comes from it, so it does not have to re-read the 131 MB it is about to consume
+  uint32_t amax[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) amax[i] = 0u;
   float bsum[10];
 #pragma unroll
   for (int i = 0; i < 10; ++i) bsum[i] = 0.f;
@@ -913,20 +930,24 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
         for (int g = 0; g < 4; ++g) {
           const float v0 = a[0][4 * g], v1 = a[0][4 * g + 1], v2 = a[0][4 * g + 2], v3 = a[0][4 * g + 3];
           const int lvl = 4 * g + 2 * h;
-          if (LAYOUT == HBR_LAYOUT_PLANAR) {
-            if (DT == HBR_F32) {
+          if (DT == HBR_F32) {
+            amax[2 * g] = max(amax[2 * g], max(__float_as_uint(v0) & 0x7fffffffu, __float_as_uint(v1) & 0x7fffffffu));
+            amax[2 * g + 1] = max(amax[2 * g + 1], max(__float_as_uint(v2) & 0x7fffffffu, __float_as_uint(v3) & 0x7fffffffu));
+            if (LAYOUT == HBR_LAYOUT_PLANAR) {
               ((float2*)dfd.p)[(size_t)lvl * fs.N + n] = make_float2(v0, v1);
               ((float2*)dfd.p)[(size_t)(lvl + 1) * fs.N + n] = make_float2(v2, v3);
             } else {
-              ((uint32_t*)dfd.p)[(size_t)lvl * fs.N + n] = pack_bf16x2(v0, v1);
-              ((uint32_t*)dfd.p)[(size_t)(lvl + 1) * fs.N + n] = pack_bf16x2(v2, v3);
+              *(float4*)((float*)dfd.p + (size_t)n * dfd.stride + 2 * lvl) = make_float4(v0, v1, v2, v3);
             }
           } else {
-            if (DT == HBR_F32) {
-              *(float4*)((float*)dfd.p + (size_t)n * dfd.stride + 2 * lvl) = make_float4(v0, v1, v2, v3);
+            const uint32_t p01 = pack_bf16x2(v0, v1), p23 = pack_bf16x2(v2, v3);  // the maxima are of the ROUNDED values
+            amax[2 * g] = max(amax[2 * g], max((p01 << 16) & 0x7fffffffu, p01 & 0x7fff0000u));
+            amax[2 * g + 1] = max(amax[2 * g + 1], max((p23 << 16) & 0x7fffffffu, p23 & 0x7fff0000u));
+            if (LAYOUT == HBR_LAYOUT_PLANAR) {
+              ((uint32_t*)dfd.p)[(size_t)lvl * fs.N + n] = p01;
+              ((uint32_t*)dfd.p)[(size_t)(lvl + 1) * fs.N + n] = p23;
             } else {
-              uint2 u = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
-              *(uint2*)((uint16_t*)dfd.p + (size_t)n * dfd.stride + 2 * lvl) = u;
+              *(uint2*)((uint16_t*)dfd.p + (size_t)n * dfd.stride + 2 * lvl) = make_uint2(p01, p23);
             }
           }
         }
@@ -945,6 +966,17 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
     for (int q = 0; q < 16; ++q) mine[(l * 16 + q) * 64] = acc[l][q];
 #pragma unroll
   for (int i = 0; i < 10; ++i) mine[(NLAYER * 16 + i) * 64] = bsum[i];
+  if (dfd.abs_part) {  // the wave's maxima: reduce over the 32 lanes of each half, lanes 0 and 32 store their 8 levels
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) amax[i] = max(amax[i], (uint32_t)__shfl_xor((int)amax[i], o));
+    }
+    if ((lane & 31) == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dfd.abs_part[(size_t)(4 * (i >> 1) + 2 * h + (i & 1)) * kAbsWaves + blockIdx.x * 4 + wv] = amax[i];
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -990,24 +1022,27 @@ static int launch_fwd(int dt, uint32_t blocks, hipStream_t st, const char* img, 
 
 template <class P, int LAYOUT, int DT, bool WLDS>
 static int launch_bwd_fused(uint32_t ntiles, hipStream_t st, const char* img, FeatSrc fs, PeSrc ps, const float* dout,
-                            DFeatDst dfd, float* dparams) {
+                            DFeatDst dfd, float* dparams, float* absmax_out) {
   using T = Tab<P>;
   const int lds = Xch<P>::BYTES + (WLDS ? T::IMG_BYTES : 0);
   uint32_t blocks = (ntiles + 3) / 4;
   if (blocks > kMaxBwdBlocks) blocks = kMaxBwdBlocks;  // one workgroup per CU; each sweeps its share of the tiles in rounds of four
   float* slabs = (float*)(const_cast<char*>(img) + slab_offset_bytes(T::IMG_BYTES));  // behind the fragment image in `ws`
+  const bool want_abs = absmax_out && dfd.p;
+  dfd.abs_part = want_abs ? (uint32_t*)(slabs + (size_t)kMaxBwdBlocks * kSlabWg) : nullptr;  // behind the slabs
   int rc = launch_with_lds(mlp_bwd_fused_kernel<P, LAYOUT, DT, WLDS>, dim3(blocks), dim3(256), lds, st, img, fs, ps, dout, dfd, slabs);
   if (rc) return rc;
-  hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(kSlabWg / 32), dim3(256), 0, st, (const float*)slabs, (int)blocks, dparams);
+  hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(kSlabWg / 32 + (want_abs ? 1 : 0)), dim3(256), 0, st, (const float*)slabs, (int)blocks,
+                     dparams, (const uint32_t*)dfd.abs_part, absmax_out);
   return HBR_OK;
 }
 
 // single pass, dW tiles shared by the four waves of a workgroup through an LDS fragment exchange
 template <int LAYOUT, int DT>
 static int launch_bwd(int precision, uint32_t ntiles, hipStream_t st, const char* img, FeatSrc fs, PeSrc ps, const float* dout,
-                      DFeatDst dfd, float* dparams) {
-  if (precision == HBR_BF16) return launch_bwd_fused<PBf16, LAYOUT, DT, true>(ntiles, st, img, fs, ps, dout, dfd, dparams);
-  return launch_bwd_fused<PF32, LAYOUT, DT, false>(ntiles, st, img, fs, ps, dout, dfd, dparams);
+                      DFeatDst dfd, float* dparams, float* absmax_out) {
+  if (precision == HBR_BF16) return launch_bwd_fused<PBf16, LAYOUT, DT, true>(ntiles, st, img, fs, ps, dout, dfd, dparams, absmax_out);
+  return launch_bwd_fused<PF32, LAYOUT, DT, false>(ntiles, st, img, fs, ps, dout, dfd, dparams, absmax_out);
 }
 
 static int check_common(const void* feat, int layout, int64_t stride, int dt, const float* pe, int64_t N, int64_t group,
@@ -1032,7 +1067,7 @@ using namespace hbr::mlp;
 extern "C" int64_t hbr_mlp_workspace_bytes(int precision) {
   // the MFMA-fragment image of the weights, then (backward only) one weight-gradient slab per workgroup
   const int64_t img = precision == HBR_BF16 ? Tab<PBf16>::IMG_BYTES : Tab<PF32>::IMG_BYTES;
-  return slab_offset_bytes(img) + (int64_t)kMaxBwdBlocks * kSlabWg * (int64_t)sizeof(float);
+  return slab_offset_bytes(img) + (int64_t)kMaxBwdBlocks * kSlabWg * (int64_t)sizeof(float) + 16 * (int64_t)kAbsWaves * 4;
 }
 
 extern "C" int hbr_dir_encode(const float* x, int64_t rows, int d_model, int num_freq, float* out, void* stream) {
@@ -1076,7 +1111,7 @@ extern "C" int hbr_mlp_fwd(const void* feat, int layout, int64_t feat_stride, in
 
 extern "C" int hbr_mlp_bwd(const void* feat, int layout, int64_t feat_stride, int feat_dtype, const float* viewdirs_enc,
                            int64_t N, int64_t group, const float* params, int precision, const float* dout, void* dfeat,
-                           float* dparams, void* ws, int64_t ws_bytes, void* stream) {
+                           float* dfeat_absmax, float* dparams, void* ws, int64_t ws_bytes, void* stream) {
   int rc = check_common(feat, layout, feat_stride, feat_dtype, viewdirs_enc, N, group, params, precision, ws, ws_bytes);
   if (rc) return rc;
   if (!dout || !dparams || ((uintptr_t)dout & 15)) return HBR_EINVAL;
@@ -1084,17 +1119,17 @@ extern "C" int hbr_mlp_bwd(const void* feat, int layout, int64_t feat_stride, in
   hipStream_t st = (hipStream_t)stream;
   FeatSrc fs{feat, feat_stride, (uint32_t)N};
   PeSrc ps{viewdirs_enc, (uint32_t)group};
-  DFeatDst dfd{dfeat, feat_stride};
+  DFeatDst dfd{dfeat, feat_stride, nullptr};
   const uint32_t ntiles = (uint32_t)((N + 31) / 32);
   char* img = (char*)ws;
   if (precision == HBR_BF16) pack<PBf16>(params, img, st);
   else pack<PF32>(params, img, st);
   if (layout == HBR_LAYOUT_PLANAR) {
-    if (feat_dtype == HBR_F32) rc = launch_bwd<HBR_LAYOUT_PLANAR, HBR_F32>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams);
-    else rc = launch_bwd<HBR_LAYOUT_PLANAR, HBR_BF16>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams);
+    if (feat_dtype == HBR_F32) rc = launch_bwd<HBR_LAYOUT_PLANAR, HBR_F32>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams, dfeat_absmax);
+    else rc = launch_bwd<HBR_LAYOUT_PLANAR, HBR_BF16>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams, dfeat_absmax);
   } else {
-    if (feat_dtype == HBR_F32) rc = launch_bwd<HBR_LAYOUT_ROWS, HBR_F32>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams);
-    else rc = launch_bwd<HBR_LAYOUT_ROWS, HBR_BF16>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams);
+    if (feat_dtype == HBR_F32) rc = launch_bwd<HBR_LAYOUT_ROWS, HBR_F32>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams, dfeat_absmax);
+    else rc = launch_bwd<HBR_LAYOUT_ROWS, HBR_BF16>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams, dfeat_absmax);
   }
   if (rc) return rc;
   HBR_RETURN_IF_LAUNCH_FAILED();

@@ -184,7 +184,8 @@ def mlp_fwd(feat: torch.Tensor, layout: int, viewdirs_enc: torch.Tensor, group: 
 
 
 def mlp_bwd(feat: torch.Tensor, layout: int, viewdirs_enc: torch.Tensor, group: int, params: torch.Tensor, precision: int,
-            dout: torch.Tensor, dparams: torch.Tensor, need_dfeat: bool = True):
+            dout: torch.Tensor, dparams: torch.Tensor, need_dfeat: bool = True, absmax_out: Optional[torch.Tensor] = None):
+    """absmax_out: optional [16] fp32 device tensor that receives max |d feat| per level (hash_encode_bwd's dy_absmax)."""
     N, stride, dtype = _feat_desc(feat, layout)
     # d feat takes feat's layout INCLUDING its row stride (the kernel addresses both with feat_stride): a strided rows
     # view such as y[:, :32] of an [N,36] buffer gets a gradient buffer with the same 36-element pitch
@@ -192,10 +193,12 @@ def mlp_bwd(feat: torch.Tensor, layout: int, viewdirs_enc: torch.Tensor, group: 
     ws = _mlp_ws(precision, feat.device)
     dout = _f32c(dout)
     if N == 0:
+        if absmax_out is not None:
+            absmax_out.zero_()
         return dfeat
     check(lib().hbr_mlp_bwd(feat.data_ptr(), layout, stride, dtype, viewdirs_enc.data_ptr(), N, group, params.data_ptr(),
-                            precision, dout.data_ptr(), _ptr(dfeat), dparams.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
-          "hbr_mlp_bwd")
+                            precision, dout.data_ptr(), _ptr(dfeat), _ptr(absmax_out), dparams.data_ptr(), ws.data_ptr(), ws.numel(),
+                            _stream()), "hbr_mlp_bwd")
     return dfeat
 
 
@@ -365,9 +368,10 @@ class RenderFn(torch.autograd.Function):
         d_out = torch.empty_like(out)
         composite_bwd(t, out.data_ptr(), 4, out.data_ptr() + 12, 4, ctx.dn, R, S, _f32c(dCr), d_out.data_ptr(), d_out.data_ptr() + 12)
         dflat = torch.zeros_like(flat)
-        dfeat = mlp_bwd(feat, PLANAR, pe, S, flat, ctx.precision, d_out, dflat)
+        amax = torch.empty(16, dtype=torch.float32, device=o.device) if g.L == 16 else None
+        dfeat = mlp_bwd(feat, PLANAR, pe, S, flat, ctx.precision, d_out, dflat, absmax_out=amax)
         dtab = torch.zeros((g.L, g.T, g.F), dtype=torch.float32, device=o.device)
         rays = None if ctx.x is not None else (o, d, t)
-        hash_encode_bwd(g, dfeat, dtab, x=ctx.x, rays=rays, layout=PLANAR)
+        hash_encode_bwd(g, dfeat, dtab, x=ctx.x, rays=rays, layout=PLANAR, dy_absmax=amax)
         grads = tuple(dtab[i] for i in range(ctx.n_tab)) + tuple(dflat[a:b].view(shape) for (a, b, shape) in ctx.splits)
         return (None,) * 12 + grads

@@ -72,6 +72,7 @@ class HashNeRFTrainer:
         self.v = torch.zeros(n_pad, dtype=torch.float32, device=dev)
         self.g_tab = self.grad[:self.n_tab].view_as(self.tables)
         self.g_mlp = self.grad[self.n_tab:self.n_tab + MLP_PARAM_FLOATS]
+        self._amax = torch.zeros(16, dtype=torch.float32, device=dev)
         self.step_count = 0
         self.last_loss = None
         self.timers = None  # optional dict name -> list[(start_event, end_event)], filled when set by bench.py
@@ -119,7 +120,10 @@ class HashNeRFTrainer:
         d_out = torch.empty_like(out)
         ops.composite_bwd(t, out.data_ptr(), 4, out.data_ptr() + 12, 4, dn, R, S, dCr, d_out.data_ptr(), d_out.data_ptr() + 12)
         self.grad.zero_()
-        dfeat = self._timed("mlp_bwd", lambda: ops.mlp_bwd(feat, PLANAR, pe, S, self.flat, self.precision, d_out, self.g_mlp))
+        # K4 also reports max |d feat| per level: K2's fixed-point scale, without K2 re-reading the buffer for it
+        amax = self._amax if g.L == 16 else None
+        dfeat = self._timed("mlp_bwd", lambda: ops.mlp_bwd(feat, PLANAR, pe, S, self.flat, self.precision, d_out, self.g_mlp,
+                                                           absmax_out=amax))
         if self.split_scatter and g.L >= 2:
             # The step's one all-reduce, issued in three pieces that partition the flat gradient buffer: the MLP block
             # (final after K4), then the upper half of the levels while the lower half's scatter is still running.
@@ -134,13 +138,15 @@ class HashNeRFTrainer:
             def scatter_halves():  # timed as ONE hash_bwd span (both launches), like the single-launch path
                 for lo, hi, piece in ((half, g.L, self.grad[cut:nt]), (0, half, self.grad[:cut])):
                     sub = ops.HashGeom(g.scales[lo:hi], g.mu, g.sigma, g.T, g.F)
-                    ops.hash_encode_bwd(sub, dfeat[lo:hi], self.g_tab[lo:hi], rays=rays, layout=PLANAR, algo=self.scatter_algo)
+                    ops.hash_encode_bwd(sub, dfeat[lo:hi], self.g_tab[lo:hi], rays=rays, layout=PLANAR, algo=self.scatter_algo,
+                                        dy_absmax=None if amax is None else amax[lo:hi])
                     red.launch(piece)
 
             self._timed("hash_bwd", scatter_halves)
             red.finish()
         else:
-            self._timed("hash_bwd", lambda: ops.hash_encode_bwd(g, dfeat, self.g_tab, rays=rays, layout=PLANAR, algo=self.scatter_algo))
+            self._timed("hash_bwd", lambda: ops.hash_encode_bwd(g, dfeat, self.g_tab, rays=rays, layout=PLANAR, algo=self.scatter_algo,
+                                                                dy_absmax=amax))
             # the one collective of the step
             if self.world > 1:
                 torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)

@@ -129,7 +129,8 @@ int hbr_dir_encode(const float* x, int64_t rows, int d_model, int num_freq, floa
  *   out      [N,4] fp32 (r,g,b,sigma)
  *   ws       scratch of hbr_mlp_workspace_bytes(precision) bytes (about 28 MB), 16-byte aligned: the weights
  *            re-packed in MFMA-fragment order (rebuilt on every call, nothing is cached), followed by the
- *            backward's per-workgroup weight-gradient slabs (written and reduced within one hbr_mlp_bwd call)
+ *            backward's per-workgroup weight-gradient slabs and per-wave feature-gradient maxima (written and
+ *            reduced within one hbr_mlp_bwd call)
  */
 enum { HBR_MLP_PARAM_FLOATS = 14227 };
 int64_t hbr_mlp_workspace_bytes(int precision);
@@ -138,13 +139,15 @@ int hbr_mlp_fwd(const void* feat, int layout, int64_t feat_stride, int feat_dtyp
                 int precision, float* out, void* ws, int64_t ws_bytes, void* stream);
 /* backward: recomputes the forward activations from `feat`, then
  *   dout     [N,4] fp32 gradient of out
- *   dfeat    gradient wrt feat (same layout/dtype/stride as feat); may be NULL
- *   dparams  [14227] fp32, ACCUMULATED INTO
+ *   dfeat    gradient wrt feat (same layout/dtype and the same row stride `feat_stride` as feat); may be NULL
+ *   dfeat_absmax optional DEVICE [16] fp32: max |dfeat| per level (of the values as stored), for hbr_hash_encode_bwd's
+ *            dy_absmax - saves that call its own pass over dfeat; NULL or dfeat == NULL => not produced
+ *   dparams  [14227] fp32, ACCUMULATED INTO (fixed summation order: bitwise reproducible)
  */
 int hbr_mlp_bwd(const void* feat, int layout, int64_t feat_stride, int feat_dtype,
                 const float* viewdirs_enc, int64_t N, int64_t group, const float* params,
-                int precision, const float* dout, void* dfeat, float* dparams, void* ws,
-                int64_t ws_bytes, void* stream);
+                int precision, const float* dout, void* dfeat, float* dfeat_absmax, float* dparams,
+                void* ws, int64_t ws_bytes, void* stream);
 
 /* ---- a11: loss + its gradient -----------------------------------------------------------------
  * train_hash2.py:177,221 with hierarchical off: loss = 2*mean((Cr-gt)^2); dCr = 4*(Cr-gt)/(3R) * gscale.

@@ -198,8 +198,16 @@ def test_k4_shipped_instantiation_vs_oracle_autocast(ops):
     P = torch.from_numpy(flat).to(DEV)
     out = ops.mlp_fwd(feat_planar, PLANAR, pe, 1, P, BF16)
     dP = torch.zeros_like(P)
-    dfeat = ops.mlp_bwd(feat_planar, PLANAR, pe, 1, P, BF16, dout.to(DEV), dP)
+    amax = torch.full((16,), -1.0, device=DEV)
+    dfeat = ops.mlp_bwd(feat_planar, PLANAR, pe, 1, P, BF16, dout.to(DEV), dP, absmax_out=amax)
     assert dfeat.dtype == torch.bfloat16 and tuple(dfeat.shape) == (16, N, 2)
+    # the per-level maxima K4 hands to K2 are exactly those of the buffer it wrote
+    assert torch.equal(amax, dfeat.float().abs().amax(dim=(1, 2)))
+    for lay, fe in ((PLANAR, feat_planar.float()), (0, feat_bf.float().to(DEV))):  # fp32 storage, both layouts
+        a32 = torch.full((16,), -1.0, device=DEV)
+        d32 = ops.mlp_bwd(fe, lay, pe, 1, P, 0, dout.to(DEV), torch.zeros_like(P), absmax_out=a32)
+        want = d32.abs().amax(dim=(1, 2)) if lay == PLANAR else d32.reshape(N, 16, 2).abs().amax(dim=(0, 2))
+        assert torch.equal(a32, want)
 
     rel = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
