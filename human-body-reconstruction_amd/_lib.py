@@ -25,10 +25,12 @@ SIGNATURES = {
     "hbr_hash_bwd_workspace_bytes": (_l, [_l, _i, _l, _i, _i]),
     "hbr_hash_bwd_workspace_bytes_min": (_l, [_l, _i, _l, _i, _i]),
     "hbr_composite_fwd": (_i, [_p, _l, _p, _l, _p, _l, _p, _l, _l, _p, _p, _p]),
-    "hbr_composite_bwd": (_i, [_p, _l, _p, _l, _p, _l, _p, _l, _l, _p, _p, _p, _p]),
+    "hbr_composite_bwd": (_i, [_p, _l, _p, _l, _p, _l, _p, _l, _l, _p, _p, _p, _p, _p]),
+    "hbr_strat_sample": (_i, [_f, _f, _l, _p, C.c_uint64, C.c_uint64, _p, _p]),
+    "hbr_occupancy_mask": (_i, [_p, _p, _p, _p, _l, _l, _p, _i, _p, _f, _p, _p]),
     "hbr_dir_encode": (_i, [_p, _l, _i, _i, _p, _p]),
     "hbr_mlp_workspace_bytes": (_l, [_i]),
-    "hbr_mlp_fwd": (_i, [_p, _i, _l, _i, _p, _l, _l, _p, _i, _p, _p, _l, _p]),
+    "hbr_mlp_fwd": (_i, [_p, _i, _l, _i, _p, _l, _l, _p, _i, _p, _p, _p, _l, _p]),
     "hbr_mlp_bwd": (_i, [_p, _i, _l, _i, _p, _l, _l, _p, _i, _p, _p, _p, _p, _p, _l, _p]),
     "hbr_mse2_workspace_bytes": (_l, []),
     "hbr_mse2_loss_fwd_bwd": (_i, [_p, _p, _l, _f, _p, _p, _p, _p]),

@@ -90,7 +90,8 @@ __global__ __launch_bounds__(kRaysPerBlock * 64) void composite_fwd_kernel(RayIn
 // suffix sum is accumulated from the far end exactly as autograd's reverse cumsum does.
 __global__ __launch_bounds__(kRaysPerBlock * 64) void composite_bwd_kernel(RayIn in, const float* __restrict__ dCr,
                                                                            float* __restrict__ d_rgb,
-                                                                           float* __restrict__ d_sigma) {
+                                                                           float* __restrict__ d_sigma,
+                                                                           const uint8_t* __restrict__ keep) {
   __shared__ float chunk_carry[kRaysPerBlock][kMaxChunks];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
@@ -133,9 +134,11 @@ __global__ __launch_bounds__(kRaysPerBlock * 64) void composite_bwd_kernel(RayIn
     if (lane == 63) rexcl = 0.f;
     const float dp = g * Tr * e - (suffix + rexcl);
     if (s < in.S) {
-      d_sigma[(r * in.S + s) * in.sigma_stride] = live ? dp * delta : 0.f;
+      // nothing flows back through a sample the occupancy grid masked out (its sigma/rgb are constants, not MLP outputs)
+      const bool kept = !keep || keep[r * in.S + s];
+      d_sigma[(r * in.S + s) * in.sigma_stride] = (live && kept) ? dp * delta : 0.f;
       float* dc = d_rgb + (r * in.S + s) * in.rgb_stride;
-      dc[0] = w * g0; dc[1] = w * g1; dc[2] = w * g2;
+      dc[0] = kept ? w * g0 : 0.f; dc[1] = kept ? w * g1 : 0.f; dc[2] = kept ? w * g2 : 0.f;
     }
     suffix += __shfl(rincl, 0, 64);
   }
@@ -212,7 +215,7 @@ extern "C" int hbr_composite_fwd(const float* t, int64_t t_stride, const float* 
 
 extern "C" int hbr_composite_bwd(const float* t, int64_t t_stride, const float* rgb, int64_t rgb_stride, const float* sigma,
                                  int64_t sigma_stride, const float* dir_norm, int64_t R, int64_t S, const float* dCr,
-                                 float* d_rgb, float* d_sigma, void* stream) {
+                                 float* d_rgb, float* d_sigma, const uint8_t* keep, void* stream) {
   RayIn in{t, t_stride, rgb, rgb_stride, sigma, sigma_stride, dir_norm, R, S};
   int rc = check_ray_in(in);
   if (rc) return rc;
@@ -221,7 +224,7 @@ extern "C" int hbr_composite_bwd(const float* t, int64_t t_stride, const float* 
   const int64_t blocks = (R + kRaysPerBlock - 1) / kRaysPerBlock;
   if (blocks > 0x7fffffffLL) return HBR_EUNSUPPORTED;
   hipLaunchKernelGGL(composite_bwd_kernel, dim3((uint32_t)blocks), dim3(kRaysPerBlock * 64), 0, (hipStream_t)stream, in, dCr, d_rgb,
-                     d_sigma);
+                     d_sigma, keep);
   HBR_RETURN_IF_LAUNCH_FAILED();
   return HBR_OK;
 }

@@ -452,7 +452,7 @@ constexpr int kFwdWaves = 4;
 
 template <class P, int LAYOUT, int DT>
 __global__ __launch_bounds__(kFwdWaves * 64) void mlp_fwd_kernel(const char* __restrict__ gimg, FeatSrc fs, PeSrc ps,
-                                                                 float* __restrict__ out) {
+                                                                 float* __restrict__ out, const uint8_t* __restrict__ keep) {
   using T = Tab<P>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // forward fragments, then the bias block right behind them
@@ -470,7 +470,9 @@ __global__ __launch_bounds__(kFwdWaves * 64) void mlp_fwd_kernel(const char* __r
     load_tile_in<LAYOUT, DT, false>(fs, ps, nullptr, n, valid, lane >> 5, ti);
     forward_tile<P, DT>(smem, bias, ti, lane, sv);
     if (valid && lane < 32) {
-      ((float4*)out)[n] = make_float4(elu1(sv.raw[0]), elu1(sv.raw[1]), elu1(sv.raw[2]), lrelu(sv.s0));
+      // a sample whose occupancy cell is False keeps the zeros the reference initialises sigma/rgb with (vol_renderer.py:213-217)
+      const bool kept = !keep || keep[n];
+      ((float4*)out)[n] = kept ? make_float4(elu1(sv.raw[0]), elu1(sv.raw[1]), elu1(sv.raw[2]), lrelu(sv.s0)) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
 }
@@ -1013,11 +1015,11 @@ static int launch_with_lds(K k, dim3 grid, dim3 block, int lds, hipStream_t st, 
 }
 
 template <class P, int LAYOUT>
-static int launch_fwd(int dt, uint32_t blocks, hipStream_t st, const char* img, FeatSrc fs, PeSrc ps, float* out) {
+static int launch_fwd(int dt, uint32_t blocks, hipStream_t st, const char* img, FeatSrc fs, PeSrc ps, float* out, const uint8_t* keep) {
   using T = Tab<P>;
   const int lds = T::BIAS_OFF_F + T::BIAS_BYTES;
-  if (dt == HBR_F32) return launch_with_lds(mlp_fwd_kernel<P, LAYOUT, HBR_F32>, dim3(blocks), dim3(kFwdWaves * 64), lds, st, img, fs, ps, out);
-  return launch_with_lds(mlp_fwd_kernel<P, LAYOUT, HBR_BF16>, dim3(blocks), dim3(kFwdWaves * 64), lds, st, img, fs, ps, out);
+  if (dt == HBR_F32) return launch_with_lds(mlp_fwd_kernel<P, LAYOUT, HBR_F32>, dim3(blocks), dim3(kFwdWaves * 64), lds, st, img, fs, ps, out, keep);
+  return launch_with_lds(mlp_fwd_kernel<P, LAYOUT, HBR_BF16>, dim3(blocks), dim3(kFwdWaves * 64), lds, st, img, fs, ps, out, keep);
 }
 
 template <class P, int LAYOUT, int DT, bool WLDS>
@@ -1082,8 +1084,8 @@ extern "C" int hbr_dir_encode(const float* x, int64_t rows, int d_model, int num
 }
 
 extern "C" int hbr_mlp_fwd(const void* feat, int layout, int64_t feat_stride, int feat_dtype, const float* viewdirs_enc,
-                           int64_t N, int64_t group, const float* params, int precision, float* out, void* ws, int64_t ws_bytes,
-                           void* stream) {
+                           int64_t N, int64_t group, const float* params, int precision, float* out, const uint8_t* keep, void* ws,
+                           int64_t ws_bytes, void* stream) {
   int rc = check_common(feat, layout, feat_stride, feat_dtype, viewdirs_enc, N, group, params, precision, ws, ws_bytes);
   if (rc) return rc;
   if (!out || ((uintptr_t)out & 15)) return HBR_EINVAL;
@@ -1097,12 +1099,12 @@ extern "C" int hbr_mlp_fwd(const void* feat, int layout, int64_t feat_stride, in
   char* img = (char*)ws;
   if (precision == HBR_BF16) {
     pack<PBf16>(params, img, st);
-    if (layout == HBR_LAYOUT_PLANAR) rc = launch_fwd<PBf16, HBR_LAYOUT_PLANAR>(feat_dtype, blocks, st, img, fs, ps, out);
-    else rc = launch_fwd<PBf16, HBR_LAYOUT_ROWS>(feat_dtype, blocks, st, img, fs, ps, out);
+    if (layout == HBR_LAYOUT_PLANAR) rc = launch_fwd<PBf16, HBR_LAYOUT_PLANAR>(feat_dtype, blocks, st, img, fs, ps, out, keep);
+    else rc = launch_fwd<PBf16, HBR_LAYOUT_ROWS>(feat_dtype, blocks, st, img, fs, ps, out, keep);
   } else {
     pack<PF32>(params, img, st);
-    if (layout == HBR_LAYOUT_PLANAR) rc = launch_fwd<PF32, HBR_LAYOUT_PLANAR>(feat_dtype, blocks, st, img, fs, ps, out);
-    else rc = launch_fwd<PF32, HBR_LAYOUT_ROWS>(feat_dtype, blocks, st, img, fs, ps, out);
+    if (layout == HBR_LAYOUT_PLANAR) rc = launch_fwd<PF32, HBR_LAYOUT_PLANAR>(feat_dtype, blocks, st, img, fs, ps, out, keep);
+    else rc = launch_fwd<PF32, HBR_LAYOUT_ROWS>(feat_dtype, blocks, st, img, fs, ps, out, keep);
   }
   if (rc) return rc;
   HBR_RETURN_IF_LAUNCH_FAILED();

@@ -31,9 +31,16 @@ def get_od(H, W, K, c2w: torch.Tensor, find_inv: Optional[bool] = False):
     return o, d / n, n
 
 
+_strat_draws = 0  # draws taken from the device-side generator since import (the counter of the counter-based RNG)
+
+
 def strat_sampler(tn, tf, num_samples: int, exp: Optional[bool] = False, device=None) -> torch.Tensor:
     """t[S] = linspace(tn,tf,S) + U[0,1)^S * (tf-tn)/S  (helper.py:210-237); ONE jitter per sample index,
-    shared by every ray; may exceed tf.  `exp` samples uniformly in log-depth."""
+    shared by every ray; may exceed tf.  `exp` samples uniformly in log-depth.
+    On the GPU (non-exp) this is one kernel launch: the uniforms come from a counter-based generator keyed by torch's
+    CUDA seed (`torch.manual_seed` makes runs repeat) and a per-process draw counter.  On the CPU, and for `exp`, the
+    reference's torch ops are used as they are."""
+    global _strat_draws
     if device is None:
         device = "cuda" if torch.cuda.is_available() else "cpu"
     tn, tf = torch.as_tensor(tn, dtype=torch.float32), torch.as_tensor(tf, dtype=torch.float32)
@@ -41,6 +48,9 @@ def strat_sampler(tn, tf, num_samples: int, exp: Optional[bool] = False, device=
         lt = torch.linspace(float(torch.log(tn)), float(torch.log(tf)), num_samples, device=device)
         lt = lt + torch.rand_like(lt) * float(torch.log(tf) - torch.log(tn)) / num_samples
         return torch.exp(lt)
+    if torch.device(device).type == "cuda":
+        _strat_draws += 1
+        return ops.strat_sample(float(tn), float(tf), int(num_samples), device, seed=torch.cuda.initial_seed(), offset=_strat_draws)
     t = torch.linspace(float(tn), float(tf), num_samples, device=device)
     return t + torch.rand_like(t) * float(tf - tn) / num_samples
 

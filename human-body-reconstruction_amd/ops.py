@@ -171,7 +171,9 @@ def _feat_desc(feat: torch.Tensor, layout: int):
     return N, stride, dtype
 
 
-def mlp_fwd(feat: torch.Tensor, layout: int, viewdirs_enc: torch.Tensor, group: int, params: torch.Tensor, precision: int):
+def mlp_fwd(feat: torch.Tensor, layout: int, viewdirs_enc: torch.Tensor, group: int, params: torch.Tensor, precision: int,
+            keep: Optional[torch.Tensor] = None):
+    """keep: optional [N] uint8/bool occupancy mask (occupancy_mask()); rows with keep == 0 come out as zeros."""
     require_gpu(feat)
     N, stride, dtype = _feat_desc(feat, layout)
     out = torch.empty((N, 4), dtype=torch.float32, device=feat.device)
@@ -179,7 +181,7 @@ def mlp_fwd(feat: torch.Tensor, layout: int, viewdirs_enc: torch.Tensor, group: 
     if N == 0:
         return out
     check(lib().hbr_mlp_fwd(feat.data_ptr(), layout, stride, dtype, viewdirs_enc.data_ptr(), N, group, params.data_ptr(),
-                            precision, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "hbr_mlp_fwd")
+                            precision, out.data_ptr(), _ptr(keep), ws.data_ptr(), ws.numel(), _stream()), "hbr_mlp_fwd")
     return out
 
 
@@ -217,11 +219,46 @@ def composite_fwd(t, rgb, rgb_stride, sigma, sigma_stride, dir_norm, R, S, want_
     return Cr, wts
 
 
-def composite_bwd(t, rgb, rgb_stride, sigma, sigma_stride, dir_norm, R, S, dCr, d_rgb, d_sigma):
+def composite_bwd(t, rgb, rgb_stride, sigma, sigma_stride, dir_norm, R, S, dCr, d_rgb, d_sigma, keep=None):
     if R == 0:
         return
     check(lib().hbr_composite_bwd(t.data_ptr(), _t_stride(t, S), rgb, rgb_stride, sigma, sigma_stride, _ptr(dir_norm), R, S, dCr.data_ptr(),
-                                  d_rgb, d_sigma, _stream()), "hbr_composite_bwd")
+                                  d_rgb, d_sigma, _ptr(keep), _stream()), "hbr_composite_bwd")
+
+
+def strat_sample(tn: float, tf: float, S: int, device, u: Optional[torch.Tensor] = None, seed: int = 0, offset: int = 0) -> torch.Tensor:
+    """t[S] = linspace(tn,tf,S) + u*(tf-tn)/S in one launch (helper.py:234-235).  u [S] on the device, or None: drawn on
+    the device by a counter-based generator from (seed, offset)."""
+    t = torch.empty(S, dtype=torch.float32, device=device)
+    require_gpu(t)
+    if u is not None:
+        u = _f32c(u)
+        if u.numel() != S or not u.is_cuda:
+            raise HbrError("u must hold S floats on the device")
+    check(lib().hbr_strat_sample(float(tn), float(tf), S, _ptr(u), int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), t.data_ptr(),
+                                 _stream()), "hbr_strat_sample")
+    return t
+
+
+def occupancy_mask(grid: torch.Tensor, mu, sigma_val: float, x: Optional[torch.Tensor] = None, rays=None) -> torch.Tensor:
+    """keep [N] uint8 = Volume_Renderer.get_mask (vol_renderer.py:133-140) for explicit points x [N,3] or rays (o, d, t)."""
+    require_gpu(grid)
+    if grid.dtype not in (torch.bool, torch.uint8) or grid.dim() != 3 or not grid.is_contiguous() or len(set(grid.shape)) != 1:
+        raise HbrError("occupancy grid must be a contiguous cubic bool/uint8 tensor")
+    import ctypes as C
+    if x is not None:
+        x = _f32c(x)
+        R, S = x.shape[0], 1
+        o = d = t = None
+    else:
+        o, d, t = (_f32c(a) for a in rays)
+        R, S = o.shape[0], t.shape[0]
+    keep = torch.empty(R * S, dtype=torch.uint8, device=grid.device)
+    if R * S:
+        m = (C.c_float * 3)(*[float(v) for v in mu])
+        check(lib().hbr_occupancy_mask(_ptr(x), _ptr(o), _ptr(d), _ptr(t), R, S, grid.data_ptr(), grid.shape[0], m, float(sigma_val),
+                                       keep.data_ptr(), _stream()), "hbr_occupancy_mask")
+    return keep
 
 
 def mse2_loss(Cr: torch.Tensor, gt: torch.Tensor, gscale: float = 1.0, want_grad: bool = True):
@@ -342,7 +379,7 @@ class RenderFn(torch.autograd.Function):
     hierarchical pass (vol_renderer.py:226-242); points o + d*t are then materialised once."""
 
     @staticmethod
-    def forward(ctx, rays_o, rays_d, t, dir_norm, geom, stacked, flat, precision, num_freq, splits, feat_dtype, n_tab, *params):
+    def forward(ctx, rays_o, rays_d, t, dir_norm, geom, stacked, flat, precision, num_freq, splits, feat_dtype, n_tab, keep, *params):
         o, d, t = _f32c(rays_o.detach()), _f32c(rays_d.detach()), _f32c(t.detach())
         R, S = o.shape[0], t.shape[-1]
         dn = _dir_norm_arg(dir_norm, R, o.device)
@@ -352,10 +389,10 @@ class RenderFn(torch.autograd.Function):
         else:
             x, rays = (o[:, None, :] + d[:, None, :] * t[:, :, None]).reshape(-1, 3).contiguous(), None
         feat = hash_encode_fwd(geom, stacked, x=x, rays=rays, layout=PLANAR, dtype=feat_dtype)
-        out = mlp_fwd(feat, PLANAR, pe, S, flat, precision)
+        out = mlp_fwd(feat, PLANAR, pe, S, flat, precision, keep=keep)  # keep: occupancy mask [N] or None (all kept)
         Cr, wts = composite_fwd(t, out.data_ptr(), 4, out.data_ptr() + 12, 4, dn, R, S)
         ctx.save_for_backward(o, d, t, pe, feat, out, flat)  # flat: see MlpFn
-        ctx.x = x
+        ctx.x, ctx.keep = x, keep
         ctx.dn, ctx.geom, ctx.precision, ctx.splits, ctx.n_tab = dn, geom, precision, splits, n_tab
         ctx.mark_non_differentiable(wts, out)
         return Cr, wts, out
@@ -366,7 +403,8 @@ class RenderFn(torch.autograd.Function):
         g = ctx.geom
         R, S = o.shape[0], t.shape[-1]
         d_out = torch.empty_like(out)
-        composite_bwd(t, out.data_ptr(), 4, out.data_ptr() + 12, 4, ctx.dn, R, S, _f32c(dCr), d_out.data_ptr(), d_out.data_ptr() + 12)
+        composite_bwd(t, out.data_ptr(), 4, out.data_ptr() + 12, 4, ctx.dn, R, S, _f32c(dCr), d_out.data_ptr(), d_out.data_ptr() + 12,
+                      keep=ctx.keep)
         dflat = torch.zeros_like(flat)
         amax = torch.empty(16, dtype=torch.float32, device=o.device) if g.L == 16 else None
         dfeat = mlp_bwd(feat, PLANAR, pe, S, flat, ctx.precision, d_out, dflat, absmax_out=amax)
@@ -374,4 +412,4 @@ class RenderFn(torch.autograd.Function):
         rays = None if ctx.x is not None else (o, d, t)
         hash_encode_bwd(g, dfeat, dtab, x=ctx.x, rays=rays, layout=PLANAR, dy_absmax=amax)
         grads = tuple(dtab[i] for i in range(ctx.n_tab)) + tuple(dflat[a:b].view(shape) for (a, b, shape) in ctx.splits)
-        return (None,) * 12 + grads
+        return (None,) * 13 + grads

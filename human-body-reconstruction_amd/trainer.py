@@ -26,7 +26,6 @@ from .dist import StagedAllReduce
 from ._lib import BF16, F32, MLP_PARAM_FLOATS, PLANAR
 from .encoder import PositionalEncoder
 from .hash_encoding import HashEncoder
-from .helper import strat_sampler
 from .test_hash import MLP_3D
 
 
@@ -39,7 +38,8 @@ class HashNeRFTrainer:
     def __init__(self, encoder: HashEncoder, mlp: MLP_3D, near: float = 2.0, far: float = 6.0, num_samples: int = 128,
                  total_steps: int = 100000, lr_embed: float = 0.05, lr_mlp: float = 0.005, eta_min: float = 1e-4,
                  weight_decay_mlp: float = 0.01, precision: int = BF16, feat_dtype: Optional[int] = None, num_freq: int = 4,
-                 process_group=None, scatter_algo: int = 0, overlap_comm: bool = True, split_scatter: Optional[bool] = None):
+                 process_group=None, scatter_algo: int = 0, overlap_comm: bool = True, split_scatter: Optional[bool] = None,
+                 seed: int = 0):
         self.enc, self.mlp = encoder, mlp
         self.near, self.far, self.S = float(near), float(far), int(num_samples)
         self.total_steps = int(total_steps)
@@ -52,6 +52,7 @@ class HashNeRFTrainer:
             feat_dtype = precision
         self.precision, self.feat_dtype, self.num_freq = precision, feat_dtype, num_freq
         self.scatter_algo = scatter_algo
+        self.seed = int(seed)
         self.overlap_comm = overlap_comm
         self.pg = process_group
         self.world = 1
@@ -98,7 +99,9 @@ class HashNeRFTrainer:
         return r
 
     def sample_t(self, device) -> torch.Tensor:
-        return strat_sampler(self.near, self.far, self.S, device=device)
+        """This step's shared depths t[S]: one launch, jitter drawn on the device from (seed, step) - every rank that
+        was built with the same `seed` samples the same depths, as the sharded step requires."""
+        return ops.strat_sample(self.near, self.far, self.S, device, seed=self.seed, offset=self.step_count)
 
     # ---- one optimisation step ------------------------------------------------------------------
     def step(self, rays_o, rays_d, dir_norm, gt, t: Optional[torch.Tensor] = None):
@@ -168,7 +171,7 @@ class HashNeRFTrainer:
         """Image-write path (train_hash2.py:277-292): 16000-ray chunks, unmasked branch."""
         S = num_samples or self.S
         if t is None:
-            t = strat_sampler(self.near, self.far, S, device=rays_o.device)
+            t = ops.strat_sample(self.near, self.far, S, rays_o.device, seed=self.seed, offset=(1 << 40) + self.step_count)
         outs = []
         for i in range(0, rays_o.shape[0], chunk):
             o, d = rays_o[i:i + chunk].contiguous(), rays_d[i:i + chunk].contiguous()

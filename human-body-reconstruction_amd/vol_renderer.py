@@ -16,7 +16,7 @@ from . import ops
 from ._lib import F32, HbrError
 from .encoder import PositionalEncoder
 from .hash_encoding import HashEncoder
-from .helper import calc_color, strat_sampler
+from .helper import strat_sampler
 from .test_hash import MLP_3D
 
 
@@ -44,7 +44,7 @@ class Volume_Renderer():
         self.use_sdf = use_sdf
         self.var_model = var_model
         self.feat_dtype = F32       # dtype of the planar feature buffer between K1 and K3 (F32 | BF16)
-        self._grid_version = self.bool_grid._version
+        self._grid_key = None       # (tensor identity, storage, version) the cached all-true answer belongs to
         self._grid_all_true = True
         self.fine_rng = None        # optional callable -> (u [R,S], samples01 [S]) replacing torch.rand in the hierarchical pass
         self.last_t_fine = None
@@ -71,9 +71,14 @@ class Volume_Renderer():
         return self.bool_grid[idx[..., 0], idx[..., 1], idx[..., 2]]
 
     def _mask_is_trivial(self) -> bool:
-        if self.bool_grid._version != self._grid_version:
-            self._grid_all_true = bool(self.bool_grid.all())
-            self._grid_version = self.bool_grid._version
+        """All cells True (the shipped trainer never clears one) => the lookup can be skipped.  The answer is
+        cached per grid CONTENT: in-place writes bump `_version`, and a rebound `vr.bool_grid = other` changes the
+        tensor's identity and storage, so either invalidates it."""
+        g = self.bool_grid
+        key = (id(g), g.data_ptr(), g._version)
+        if key != self._grid_key:
+            self._grid_all_true = bool(g.all())
+            self._grid_key = key
         return self._grid_all_true
 
     # ---- render (vol_renderer.py:141-245) -----------------------------------------------------
@@ -96,10 +101,13 @@ class Volume_Renderer():
         if update_mask is True and self.reset_mask is True:  # vol_renderer.py:201-203
             self.bool_grid[...] = False
             self.reset_mask = False
+        # masked branch (vol_renderer.py:209-221) unless update_mask, or the grid has no False cell to look up
+        keep = None
         if update_mask is not True and not self._mask_is_trivial():
-            Cr = self._render_masked(mlp, rays_d, rays_o, t, dir_norm)
-        else:
-            Cr = self._render_fused(mlp, rays_d, rays_o, t, dir_norm)
+            g = self.bool_grid if self.bool_grid.is_contiguous() else self.bool_grid.contiguous()
+            mu = self.mu.detach().float().reshape(-1).cpu().tolist()
+            keep = ops.occupancy_mask(g, mu * 3 if len(mu) == 1 else mu, float(self.sigma_val), rays=(rays_o, rays_d, t))
+        Cr = self._render_fused(mlp, rays_d, rays_o, t, dir_norm, keep)
         if hierarchical is True:
             from .hierarchical import render_fine
             Cf = render_fine(self, mlp, rays_d, rays_o, t, self._last_wts, num_samples, dir_norm)
@@ -107,31 +115,16 @@ class Volume_Renderer():
             Cf = Cr
         return Cr, Cf, None
 
-    def _render_fused(self, mlp, rays_d, rays_o, t, dir_norm):
+    def _render_fused(self, mlp, rays_d, rays_o, t, dir_norm, keep=None):
         enc = self.Pos_encode
         stacked = enc.stacked_tables()
         flat, splits = mlp.flat_params()
         tabs = [lvl.weight for lvl in enc.Embedding_list]
         Cr, wts, out = ops.RenderFn.apply(rays_o, rays_d, t, dir_norm, enc.geometry(), stacked, flat,
                                           ops.precision_from_autocast(), self.Dir_encode.max_seq_len, splits, self.feat_dtype,
-                                          len(tabs), *tabs, *mlp._ordered())
+                                          len(tabs), keep, *tabs, *mlp._ordered())
         R, S = rays_o.shape[0], t.shape[0]
         self._last_wts = wts
         o4 = out.view(R, S, 4)
         self.last_sigma, self.last_rgb = o4[..., 3], o4[..., 0:3]
-        return Cr
-
-    def _render_masked(self, mlp, rays_d, rays_o, t, dir_norm):
-        """The reference's masked branch (vol_renderer.py:211-221) for a non-trivial occupancy grid: samples whose
-        grid cell is False contribute sigma = rgb = 0.  Composed from the modular ops (encoder rows layout)."""
-        R, S = rays_o.shape[0], t.shape[0]
-        pts = (rays_o[..., None, :] + rays_d[..., None, :] * t[None, :, None]).reshape(-1, 3)
-        mask = self.get_mask(pts)
-        feat = self.Pos_encode(pts)
-        dirs = self.Dir_encode(rays_d[:, None, :].expand(R, S, 3).reshape(-1, 3))
-        out = mlp(feat, dirs) * mask[:, None]
-        sigma, rgb = out[:, 3].reshape(R, S), out[:, 0:3].reshape(R, S, 3)
-        Cr, wts, _ = calc_color(t, rgb, sigma, dir_norm)
-        self._last_wts = wts[..., 0]
-        self.last_sigma, self.last_rgb = sigma, rgb
         return Cr

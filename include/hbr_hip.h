@@ -48,6 +48,23 @@ const char* hbr_strerror(int code);
 /* 1 if a HIP device with gcnArchName gfx950 is visible, 0 otherwise */
 int hbr_device_ok(void);
 
+/* ---- K0: sampling along rays ------------------------------------------------------------------
+ * hbr_strat_sample replaces strat_sampler, helper.py:210-237 (non-exp branch):
+ *   t[s] = linspace(tn, tf, S)[s] + (u[s] * (tf - tn)) / S  - one jitter per sample index, shared by all rays.
+ *   u   DEVICE [S] uniform draws in [0,1), or NULL: drawn on the device by Philox4x32-10 from (seed, offset, s),
+ *       24-bit uniforms - reproducible across ranks and runs without shared generator state
+ *   t   DEVICE [S] out
+ * hbr_occupancy_mask replaces Volume_Renderer.get_mask, vol_renderer.py:133-140:
+ *   keep[n] = grid[cx,cy,cz], c = trunc(((p - mu)/sigma_val) * G); points as in K1 (x, or rays_o/rays_d/t)
+ *   grid DEVICE [G,G,G] bytes (a torch.bool tensor), read live; keep DEVICE [N] bytes out.
+ *   A negative index counts from the end (torch indexing); outside [-G, G) - where torch raises - is "not kept".
+ */
+int hbr_strat_sample(float tn, float tf, int64_t S, const float* u, uint64_t seed, uint64_t offset, float* t,
+                     void* stream);
+int hbr_occupancy_mask(const float* x, const float* rays_o, const float* rays_d, const float* t, int64_t R,
+                       int64_t S, const uint8_t* grid, int G, const float* mu_host, float sigma_val,
+                       uint8_t* keep, void* stream);
+
 /* ---- K1: multiresolution hash-grid encode --------------------------------------------------
  * Replaces HashEncoder.forward, hash_encoding.py:146-170 (per level: scale :153-154, trunc :157,
  * frac :158, 8 corners :135, spatial hash :49-53, embedding gather :163, trilinear :142-144).
@@ -105,10 +122,12 @@ int64_t hbr_hash_bwd_workspace_bytes_min(int64_t N, int L, int64_t T, int F, int
 int hbr_composite_fwd(const float* t, int64_t t_stride, const float* rgb, int64_t rgb_stride, const float* sigma,
                       int64_t sigma_stride, const float* dir_norm, int64_t R, int64_t S, float* Cr,
                       float* wts, void* stream);
-/* d_rgb / d_sigma use the same strides as their forward counterparts */
+/* d_rgb / d_sigma use the same strides as their forward counterparts.
+ * keep: optional DEVICE [R*S] bytes (hbr_occupancy_mask): gradients of samples with keep == 0 are written as 0
+ * (vol_renderer.py:209-221: their sigma/rgb are zeros, not model outputs) */
 int hbr_composite_bwd(const float* t, int64_t t_stride, const float* rgb, int64_t rgb_stride, const float* sigma,
                       int64_t sigma_stride, const float* dir_norm, int64_t R, int64_t S,
-                      const float* dCr, float* d_rgb, float* d_sigma, void* stream);
+                      const float* dCr, float* d_rgb, float* d_sigma, const uint8_t* keep, void* stream);
 
 /* ---- a7: view-direction encoding ---------------------------------------------------------------
  * Replaces PositionalEncoder.forward, encoder.py:25-32: for each row and coordinate c,
@@ -127,6 +146,7 @@ int hbr_dir_encode(const float* x, int64_t rows, int d_model, int num_freq, floa
  *            col0.W[64,39] col0.b[64] col2.W[64,64] col2.b[64] col4.W[3,64] col4.b[3]   (14227 floats)
  *   precision HBR_F32 (exact-fp32 MFMA, v_mfma_f32_32x32x2_f32) or HBR_BF16 (bf16 operands, fp32 accumulate)
  *   out      [N,4] fp32 (r,g,b,sigma)
+ *   keep     (hbr_mlp_fwd) optional DEVICE [N] bytes (hbr_occupancy_mask): out rows with keep == 0 are written as zeros
  *   ws       scratch of hbr_mlp_workspace_bytes(precision) bytes (about 28 MB), 16-byte aligned: the weights
  *            re-packed in MFMA-fragment order (rebuilt on every call, nothing is cached), followed by the
  *            backward's per-workgroup weight-gradient slabs and per-wave feature-gradient maxima (written and
@@ -136,7 +156,7 @@ enum { HBR_MLP_PARAM_FLOATS = 14227 };
 int64_t hbr_mlp_workspace_bytes(int precision);
 int hbr_mlp_fwd(const void* feat, int layout, int64_t feat_stride, int feat_dtype,
                 const float* viewdirs_enc, int64_t N, int64_t group, const float* params,
-                int precision, float* out, void* ws, int64_t ws_bytes, void* stream);
+                int precision, float* out, const uint8_t* keep, void* ws, int64_t ws_bytes, void* stream);
 /* backward: recomputes the forward activations from `feat`, then
  *   dout     [N,4] fp32 gradient of out
  *   dfeat    gradient wrt feat (same layout/dtype and the same row stride `feat_stride` as feat); may be NULL

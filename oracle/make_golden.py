@@ -262,7 +262,7 @@ def main():
     cap = {}
     orig_cc = ref.vol_renderer.calc_color
 
-    def spy(**kw):
+    def spy(**kw):  # (`cap` is looked up at call time: G13 rebinds it)
         cap["sigma"] = kw["sigma"].detach().clone().numpy()
         cap["rgb"] = kw["rgb"].detach().clone().numpy()
         return orig_cc(**kw)
@@ -332,6 +332,32 @@ def main():
                         n_samples=S, tn=2.0, tf=6.0, device="cpu")
     g12.update(hs_weights=wts_in.numpy(), hs_u=u11.numpy(), hs_samples01=s11.numpy(), hs_rays=rays_f.numpy(), hs_t=t_f.numpy())
     np.savez_compressed(os.path.join(OUT, "g12_hierarchical.npz"), **g12)
+
+    # ---------------- G13: masked branch with a MIXED occupancy grid (vol_renderer.py:133-140,209-221) ----------
+    # The shipped trainer never clears grid cells, so the masked assign is exercised here with a grid that
+    # is False in a third of its 256^3 cells: blocks of 8^3 cells with (bx + 2*by + 3*bz) % 3 == 0.  The pattern is a
+    # formula so that the 16 MiB grid does not have to travel; the fixture records what the reference renders with it.
+    enc = build_encoder(ref, tables, 2048.0, 16, mu, sigma)          # original (pre-step) weights
+    mlp = torch.nn.DataParallel(build_mlp(ref, params))
+    vr = ref.vol_renderer.Volume_Renderer(H=8, W=8, K=Kd, near=2.0, far=6.0, device="cpu", Pos_encode=enc,
+                                          Dir_encode=pe, max_dim=2 ** 10, sigma_val=torch.tensor(float(sigma)),
+                                          mu=torch.from_numpy(mu))
+    gi = torch.arange(vr.grid_size) // 8
+    vr.bool_grid[...] = ((gi[:, None, None] + 2 * gi[None, :, None] + 3 * gi[None, None, :]) % 3) != 0
+    cap = {}
+    ref.vol_renderer.calc_color = spy
+    Cr_m, Cf_m, _ = quiet(vr.vol_render, mlp, dvec, o, num_samples=S, t=torch.from_numpy(t), update_mask=False,
+                          dir_norm=dn, hierarchical=False)
+    ref.vol_renderer.calc_color = orig_cc
+    loss_m = crit(Cr_m, gt) + crit(Cf_m, gt)
+    loss_m.backward()
+    pts13 = (o[:, None, :] + dvec[:, None, :] * torch.from_numpy(t)[None, :, None]).reshape(-1, 3)
+    g13 = dict(mask=vr.get_mask(pts13).numpy(), Cr=Cr_m.detach().numpy(), sig_out=cap["sigma"], rgb_out=cap["rgb"],
+               loss=loss_m.item(), dtables=np.stack([enc.Embedding_list[l].weight.grad.numpy() for l in range(L)]),
+               grid_size=vr.grid_size)
+    for name, p in mlp.module.named_parameters():
+        g13["g." + name] = p.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "g13_masked_render.npz"), **g13)
 
     # ---------------- G10: PSNR + bounding box -----------------------------------------
     a = torch.from_numpy(f32(rng.uniform(0, 1, (50, 3))))

@@ -265,6 +265,39 @@ def render(o, d, t, dir_norm, tables, scales, mu, sigma, mlp_params, num_freq: i
     return Cr, sig, rgb
 
 
+def occupancy_mask(pts: torch.Tensor, grid: torch.Tensor, mu, sigma_val) -> torch.Tensor:
+    """Volume_Renderer.get_mask (vol_renderer.py:133-140): cell = trunc(((p - mu) / sigma_val) * grid_size) per axis
+    (three separately rounded fp32 ops, `.long()` truncates toward zero), then bool_grid[cx, cy, cz]."""
+    G = grid.shape[0]
+    c = (((pts - mu) / sigma_val) * G).long()
+    return grid[c[..., 0], c[..., 1], c[..., 2]]
+
+
+def block_pattern_grid(G: int = 256) -> torch.Tensor:
+    """The mixed occupancy grid of golden G13: blocks of 8^3 cells, False where (bx + 2 by + 3 bz) % 3 == 0."""
+    b = torch.arange(G) // 8
+    return ((b[:, None, None] + 2 * b[None, :, None] + 3 * b[None, None, :]) % 3) != 0
+
+
+def render_masked(o, d, t, dir_norm, tables, scales, mu, sigma, mlp_params, grid, grid_mu, grid_sigma, num_freq: int = 4):
+    """vol_render's masked branch (vol_renderer.py:209-221): the MLP runs on the kept samples only; sigma and rgb of
+    the others are the zeros they were initialised with (so nothing flows back through them).
+    Returns (Cr, sigma [R,S], rgb [R,S,3], mask [N])."""
+    R, S = o.shape[0], t.shape[0]
+    pts = sample_points(o, d, t).reshape(-1, 3)
+    mask = occupancy_mask(pts, grid, grid_mu, grid_sigma)
+    feat = hash_encode(pts, tables, scales, mu, sigma)
+    dirs = dir_encode(d[:, None, :].expand(R, S, 3).reshape(-1, 3), num_freq)
+    out = mlp_forward(feat[mask], dirs[mask], mlp_params)
+    sig = torch.zeros((R * S, 1), dtype=out.dtype)
+    rgb = torch.zeros((R * S, 3), dtype=out.dtype)
+    sig[mask] = out[:, 3:4]
+    rgb[mask] = out[:, 0:3]
+    sig, rgb = sig.reshape(R, S), rgb.reshape(R, S, 3)
+    Cr, _ = composite(t, rgb, sig, dir_norm)
+    return Cr, sig, rgb, mask
+
+
 def train_loss(Cr: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
     """train_hash2.py:177,221: MSE(Cr,gt)+MSE(Cf,gt) with Cf is Cr => 2*MSE."""
     return 2 * torch.mean((Cr - gt) ** 2)

@@ -59,7 +59,14 @@ def test_argument_validation_without_gpu(L):
     # per-ray t stride shorter than S
     assert lib.hbr_composite_fwd(8, 3, 8, 3, 8, 1, None, 4, 16, 8, None, None) == -1
     # workspace too small
-    assert lib.hbr_mlp_fwd(16, 0, 32, 0, 16, 4, 1, 16, 1, 16, 16, 10, None) == -4
+    assert lib.hbr_mlp_fwd(16, 0, 32, 0, 16, 4, 1, 16, 1, 16, None, 16, 10, None) == -4
+    # K0: null outputs / bad grid size; K2 (validation precedes any launch): algo 2 without its workspace, T too large
+    assert lib.hbr_strat_sample(2.0, 6.0, 16, None, 0, 0, None, None) == -1
+    assert lib.hbr_occupancy_mask(8, None, None, None, 4, 1, 8, 0, mu, 1.0, 8, None) == -1
+    assert lib.hbr_hash_encode_bwd(8, None, None, None, 70000, 1, 8, 1, 0, 0, None, sc, mu, 1.0, 16, 1024, 2, 8, 2, None, 0, None) == -4
+    assert lib.hbr_hash_encode_bwd(8, None, None, None, 70000, 1, 8, 1, 0, 0, None, sc, mu, 1.0, 16, 2 ** 29, 2, 8, 2, 8, 64, None) == -2
+    assert lib.hbr_hash_bwd_workspace_bytes(2048000, 16, 65536, 2, 0) > lib.hbr_hash_bwd_workspace_bytes_min(2048000, 16, 65536, 2, 0) > 0
+    assert lib.hbr_hash_bwd_workspace_bytes(1000, 16, 65536, 2, 0) == 0  # auto: the global-atomics kernel at this size
     # adam: misaligned pointer
     assert lib.hbr_adam_step(4, 16, 16, 16, 8, 0.1, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, None) == -1
 

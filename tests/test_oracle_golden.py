@@ -210,3 +210,27 @@ def test_g12_hierarchical_sampler_and_render():
     assert np.allclose(got, g["dtables"], rtol=1e-3, atol=1e-5 * np.abs(g["dtables"]).max())
     for k, p in params.items():
         assert np.allclose(p.grad.numpy(), g["g." + k], rtol=1e-3, atol=1e-5 * np.abs(g["g." + k]).max()), k
+
+
+def test_g13_masked_render_with_mixed_occupancy_grid():
+    """vol_render's masked branch with a grid that is False in a third of its cells (reference vol_renderer.py:133-140,
+    209-221): mask, sigma/rgb handed to calc_color, Cr, loss and every gradient."""
+    g = load_golden("g13_masked_render.npz")
+    g8 = load_golden("g8_render_step.npz")
+    tabs, params, scales = _g8_state(g8)
+    mu, sigma = T_(g8["mu"]), torch.tensor(float(g8["sigma"]))
+    o, d, dn, gt, t = (T_(g8[k]) for k in ("o", "d", "dir_norm", "gt", "t"))
+    grid = ref_cpu.block_pattern_grid(int(g["grid_size"]))
+    Cr, sig, rgb, mask = ref_cpu.render_masked(o, d, t, dn, tabs, scales, mu, sigma, params, grid, mu, sigma)
+    assert np.array_equal(mask.numpy(), g["mask"]) and 0.3 < 1 - mask.float().mean().item() < 0.4
+    assert np.allclose(sig.detach().numpy(), g["sig_out"], rtol=1e-4, atol=1e-5)
+    assert np.allclose(rgb.detach().numpy(), g["rgb_out"], rtol=1e-4, atol=1e-5)
+    assert np.array_equal(sig.detach().numpy().reshape(-1)[~g["mask"]], np.zeros((~g["mask"]).sum(), np.float32))
+    assert np.allclose(Cr.detach().numpy(), g["Cr"], rtol=1e-4, atol=1e-5)
+    loss = ref_cpu.train_loss(Cr, gt)
+    assert abs(loss.item() - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    loss.backward()
+    got = np.stack([t_.grad.numpy() for t_ in tabs])
+    assert np.allclose(got, g["dtables"], rtol=1e-3, atol=1e-5 * np.abs(g["dtables"]).max())
+    for k, p in params.items():
+        assert np.allclose(p.grad.numpy(), g["g." + k], rtol=1e-3, atol=1e-5 * np.abs(g["g." + k]).max()), k
