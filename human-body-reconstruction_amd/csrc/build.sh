@@ -7,7 +7,7 @@ OUT="$HERE/../libhbr_hip.so"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wno-unused-value -I"$ROOT/include" -I"$HERE")
 mkdir -p "$HERE/build"
 pids=()
-for f in c_api sample hash_encode hash_scatter composite optim mlp; do
+for f in c_api sample render hash_encode hash_scatter composite optim mlp; do
   if [ ! -f "$HERE/build/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/build/$f.o" ] || [ "$HERE/hbr_common.h" -nt "$HERE/build/$f.o" ] || [ "$HERE/hash_common.h" -nt "$HERE/build/$f.o" ] || [ "$ROOT/include/hbr_hip.h" -nt "$HERE/build/$f.o" ]; then
     extra=()
     # mlp.hip: keep MFMA results in VGPRs (the VALU epilogues read every accumulator; the AGPR form costs ~650
@@ -18,5 +18,5 @@ for f in c_api sample hash_encode hash_scatter composite optim mlp; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE"/build/{c_api,sample,hash_encode,hash_scatter,composite,optim,mlp}.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE"/build/{c_api,sample,render,hash_encode,hash_scatter,composite,optim,mlp}.o
 echo "built $OUT"

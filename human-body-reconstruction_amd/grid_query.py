@@ -11,6 +11,8 @@ direction is float16 too, so its sin/cos encoding is rounded to float16.
 """
 from __future__ import annotations
 
+from typing import Optional
+
 import numpy as np
 import torch
 
@@ -20,18 +22,29 @@ from .hash_encoding import HashEncoder
 from .test_hash import MLP_3D
 
 
-def grid_coordinates(min_bound, max_bound, res: int, device) -> torch.Tensor:
-    """[res^3, 3] fp32 values of the fp16-rounded lattice, in the reference's order (nerf2mesh.py:30-40):
-    float64 `np.linspace` per axis, `np.meshgrid(x, y, z)` with its default 'xy' indexing (so the flat index is
-    (iy*res + ix)*res + iz), stacked, cast to float16."""
-    mn = np.asarray(torch.as_tensor(min_bound).cpu(), dtype=np.float64) if not isinstance(min_bound, np.ndarray) else min_bound
-    mx = np.asarray(torch.as_tensor(max_bound).cpu(), dtype=np.float64) if not isinstance(max_bound, np.ndarray) else max_bound
-    x = np.linspace(mn[0], mx[0], res)
-    y = np.linspace(mn[1], mx[1], res)
-    z = np.linspace(mn[2], mx[2], res)
-    X, Y, Z = np.meshgrid(x, y, z)
-    grid = torch.stack([torch.tensor(X.reshape(-1)), torch.tensor(Y.reshape(-1)), torch.tensor(Z.reshape(-1))], dim=1)
-    return grid.to(torch.float16).to(device).float()
+def _axis_linspace64(lo: float, hi: float, res: int, idx: torch.Tensor) -> torch.Tensor:
+    """np.linspace(lo, hi, res)[idx] in float64, as numpy evaluates it: step = (hi - lo) / (res - 1);
+    y = idx * step + lo (two roundings); the last sample is `hi` itself."""
+    if res == 1:
+        return torch.full(idx.shape, float(lo), dtype=torch.float64, device=idx.device)
+    step = (float(hi) - float(lo)) / (res - 1)
+    y = idx.to(torch.float64) * step + float(lo)
+    return torch.where(idx == res - 1, torch.full_like(y, float(hi)), y)
+
+
+def grid_coordinates(min_bound, max_bound, res: int, device, start: int = 0, stop: Optional[int] = None) -> torch.Tensor:
+    """Rows [start, stop) of the reference's [res^3, 3] lattice as fp32 values of fp16-rounded positions
+    (nerf2mesh.py:30-40): float64 `np.linspace` per axis, `np.meshgrid(x, y, z)` with its default 'xy' indexing - so
+    the flat index is (iy*res + ix)*res + iz - stacked, cast to float16.  Built on `device` from the flat index, so
+    a 512^3 lattice (1.3e8 points, 3.2 GB as float64 on the host in the reference) never exists as a whole."""
+    mn = np.asarray(torch.as_tensor(min_bound).detach().cpu(), dtype=np.float64).reshape(-1)
+    mx = np.asarray(torch.as_tensor(max_bound).detach().cpu(), dtype=np.float64).reshape(-1)
+    stop = res ** 3 if stop is None else min(stop, res ** 3)
+    i = torch.arange(start, stop, dtype=torch.int64, device=device)
+    iz, ix, iy = i % res, (i // res) % res, i // (res * res)
+    grid = torch.stack([_axis_linspace64(mn[0], mx[0], res, ix), _axis_linspace64(mn[1], mx[1], res, iy),
+                        _axis_linspace64(mn[2], mx[2], res, iz)], dim=1)
+    return grid.to(torch.float16).float()
 
 
 @torch.no_grad()
@@ -44,13 +57,13 @@ def query_density_grid(encoder: HashEncoder, mlp: MLP_3D, min_bound, max_bound, 
     geom = encoder.geometry()
     flat, _ = mlp.flat_params()
     prec = ops.precision_from_autocast() if precision is None else precision
-    pts = grid_coordinates(min_bound, max_bound, res, dev)
     # the reference feeds a float16 view_dir through PositionalEncoder (nerf2mesh.py:69-70,81): sin/cos come out as
     # float16 and are promoted back to fp32 by the concat in MLP_3D.forward
     pe = ops.dir_encode(torch.tensor([view_dir], dtype=torch.float32, device=dev), num_freq).half().float().contiguous()
-    out = torch.empty((pts.shape[0], 4), dtype=torch.float32, device=out_device or dev)
-    for i in range(0, pts.shape[0], batch):
-        x = pts[i:i + batch].contiguous()
+    n = res ** 3
+    out = torch.empty((n, 4), dtype=torch.float32, device=out_device or dev)
+    for i in range(0, n, batch):
+        x = grid_coordinates(min_bound, max_bound, res, dev, i, i + batch)
         feat = ops.hash_encode_fwd(geom, tables, x=x, layout=PLANAR)
         o = ops.mlp_fwd(feat, PLANAR, pe, x.shape[0], flat, prec)   # group = batch size: every point uses pe row 0
         out[i:i + batch] = o.to(out.device)

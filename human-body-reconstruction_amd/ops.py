@@ -261,6 +261,29 @@ def occupancy_mask(grid: torch.Tensor, mu, sigma_val: float, x: Optional[torch.T
     return keep
 
 
+def render_fwd(geom: HashGeom, tables: torch.Tensor, params: torch.Tensor, rays_o, rays_d, t, dir_norm=None, precision: int = F32,
+               feat_dtype: int = F32, keep: Optional[torch.Tensor] = None, want_wts: bool = False, want_out: bool = False):
+    """Inference render of R rays at the shared depths t[S] in one library call (no autograd): returns (Cr [R,3],
+    wts [R,S] or None, out [R*S,4] or None)."""
+    require_gpu(tables)
+    o, d, t = _f32c(rays_o), _f32c(rays_d), _f32c(t)
+    R, S = o.shape[0], t.shape[0]
+    dn = _dir_norm_arg(dir_norm, R, o.device)
+    Cr = torch.empty((R, 3), dtype=torch.float32, device=o.device)
+    wts = torch.empty((R, S), dtype=torch.float32, device=o.device) if want_wts else None
+    out = torch.empty((R * S, 4), dtype=torch.float32, device=o.device) if want_out else None
+    if R == 0:
+        return Cr, wts, out
+    nws = lib().hbr_render_fwd_workspace_bytes(R, S, geom.L, precision, feat_dtype, 0 if want_out else 1)
+    ws = _workspace("render_fwd", nws + 256, o.device)
+    base = (ws.data_ptr() + 255) // 256 * 256
+    sc, mu = geom.c_args()
+    check(lib().hbr_render_fwd(o.data_ptr(), d.data_ptr(), t.data_ptr(), _ptr(dn), R, S, tables.data_ptr(), sc, mu, geom.sigma, geom.L,
+                               geom.T, geom.F, params.data_ptr(), precision, feat_dtype, _ptr(keep), Cr.data_ptr(), _ptr(wts), _ptr(out),
+                               base, nws, _stream()), "hbr_render_fwd")
+    return Cr, wts, out
+
+
 def mse2_loss(Cr: torch.Tensor, gt: torch.Tensor, gscale: float = 1.0, want_grad: bool = True):
     """loss = 2*mean((Cr-gt)^2) (train_hash2.py:221, hierarchical off) and dloss/dCr * gscale."""
     require_gpu(Cr)

@@ -151,17 +151,17 @@ def main(argv=None):
                     im = ((im - im.min()) / (im.max() - im.min() + 1e-12) * 255).byte().cpu().numpy()  # train_hash2.py:297
                     Image.fromarray(im, "RGB").save(os.path.join(args.out_dir, f"hash_big_diff{epoch}_{i}.png"))
                 checkpoint.save_checkpoint(args.model_name, nerf, enc)
-                print(f"step {step}: loss {float(loss):.6f} psnr {float(calc_psnr(pred, test_rays[3])):.2f} dB")
+                print(f"step {step}: loss {float(loss.detach()):.6f} psnr {float(calc_psnr(pred, test_rays[3])):.2f} dB")
             if args.steps and step >= args.steps:
                 break
         if rank == 0:
-            print(f"Train:{step}:{float(loss):.6f}, Epoch:{epoch}, {step * args.num_batch * args.num_samples / (time.time() - t0):.3e} ray-samples/s")
+            print(f"Train:{step}:{float(loss.detach()):.6f}, Epoch:{epoch}, {step * args.num_batch * args.num_samples / (time.time() - t0):.3e} ray-samples/s")
         if args.steps and step >= args.steps:
             break
     psnr = float(calc_psnr(tr.render(test_rays[0], test_rays[1], test_rays[2], num_samples=args.num_samples), test_rays[3])) if test_rays else float("nan")
     if world > 1:
         torch.distributed.destroy_process_group()
-    return {"steps": step, "loss": float(loss), "psnr": psnr}
+    return {"steps": step, "loss": float(loss.detach()), "psnr": psnr}
 
 
 if __name__ == "__main__":

@@ -172,14 +172,12 @@ class HashNeRFTrainer:
         S = num_samples or self.S
         if t is None:
             t = ops.strat_sample(self.near, self.far, S, rays_o.device, seed=self.seed, offset=(1 << 40) + self.step_count)
+        self._bind_parameters()
         outs = []
         for i in range(0, rays_o.shape[0], chunk):
-            o, d = rays_o[i:i + chunk].contiguous(), rays_d[i:i + chunk].contiguous()
-            dn = dir_norm[i:i + chunk].reshape(-1).contiguous() if torch.is_tensor(dir_norm) else None
-            pe = ops.dir_encode(d, self.num_freq)
-            feat = ops.hash_encode_fwd(self.geom, self.tables, rays=(o, d, t), layout=PLANAR, dtype=self.feat_dtype)
-            out = ops.mlp_fwd(feat, PLANAR, pe, t.shape[0], self.flat, self.precision)
-            Cr, _ = ops.composite_fwd(t, out.data_ptr(), 4, out.data_ptr() + 12, 4, dn, o.shape[0], t.shape[0], want_wts=False)
+            dn = dir_norm[i:i + chunk].reshape(-1) if torch.is_tensor(dir_norm) else None
+            Cr, _, _ = ops.render_fwd(self.geom, self.tables, self.flat, rays_o[i:i + chunk], rays_d[i:i + chunk], t, dn,
+                                      precision=self.precision, feat_dtype=self.feat_dtype)
             outs.append(Cr)
         return torch.cat(outs)
 

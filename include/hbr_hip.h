@@ -169,6 +169,21 @@ int hbr_mlp_bwd(const void* feat, int layout, int64_t feat_stride, int feat_dtyp
                 int precision, const float* dout, void* dfeat, float* dfeat_absmax, float* dparams,
                 void* ws, int64_t ws_bytes, void* stream);
 
+/* ---- vol_render, inference half, in one call ----------------------------------------------------
+ * Replaces vol_renderer.py:141-223 under no_grad (the image-write loop, train_hash2.py:277-292; hierarchical off):
+ * direction encoding -> K1 (points o + d*t generated on chip, planar features in `feat_dtype`) -> K3 -> K5, enqueued
+ * back to back on `stream`.  Shared depths t [S]; num_freq = 4, L = 16, F = 2 (the MLP's 32 + 24 inputs).
+ *   keep   optional [R*S] bytes from hbr_occupancy_mask;  dir_norm [R] or NULL (=1)
+ *   Cr [R,3] out;  wts [R,S] out or NULL;  out [R*S,4] (r,g,b,sigma) out, or NULL to keep it inside the workspace
+ *   ws     256-byte-aligned scratch of hbr_render_fwd_workspace_bytes(R, S, L, precision, feat_dtype, out == NULL)
+ */
+int64_t hbr_render_fwd_workspace_bytes(int64_t R, int64_t S, int L, int precision, int feat_dtype, int own_out);
+int hbr_render_fwd(const float* rays_o, const float* rays_d, const float* t, const float* dir_norm, int64_t R,
+                   int64_t S, const float* tables, const float* scales_host, const float* mu_host, float sigma,
+                   int L, int64_t T, int F, const float* params, int precision, int feat_dtype,
+                   const uint8_t* keep, float* Cr, float* wts, float* out, void* ws, int64_t ws_bytes,
+                   void* stream);
+
 /* ---- a11: loss + its gradient -----------------------------------------------------------------
  * train_hash2.py:177,221 with hierarchical off: loss = 2*mean((Cr-gt)^2); dCr = 4*(Cr-gt)/(3R) * gscale.
  * loss_out: one fp32, accumulated into (caller zeroes).

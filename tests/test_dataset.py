@@ -53,3 +53,32 @@ def test_blender_and_colmap_formats(tmp_path):
     assert torch.allclose(o, o_ref.reshape(-1, 3)) and torch.allclose(d, d_ref.reshape(-1, 3), atol=1e-6)
     assert torch.allclose(nrm, n_ref.reshape(-1, 1), rtol=1e-6)
     assert torch.equal(gt[48:96], ds2[1][0].permute(1, 2, 0).reshape(-1, 3))
+
+
+def test_grid_lattice_equals_the_reference_recipe():
+    """f2: rows of the query lattice built from the flat index on the device == the reference's host recipe
+    (nerf2mesh.py:30-40): float64 np.linspace per axis, np.meshgrid (default 'xy' indexing), stack, cast to float16."""
+    from hbr_amd.grid_query import grid_coordinates
+    rng = np.random.default_rng(5)
+    for res in (1, 2, 7, 33):
+        mn, mx = rng.uniform(-5, -1, 3), rng.uniform(1, 6, 3)
+        x, y, z = (np.linspace(mn[a], mx[a], res) for a in range(3))
+        X, Y, Z = np.meshgrid(x, y, z)
+        want = torch.stack([torch.tensor(X.reshape(-1)), torch.tensor(Y.reshape(-1)), torch.tensor(Z.reshape(-1))], dim=1).to(torch.float16)
+        got = grid_coordinates(mn, mx, res, "cpu")
+        assert torch.equal(got, want.float())
+        if res == 33:  # a window of rows, as the batched query asks for them
+            assert torch.equal(grid_coordinates(mn, mx, res, "cpu", 1000, 1500), want.float()[1000:1500])
+
+
+def test_scene_writer_round_trips_through_both_loaders(tmp_path):
+    from conftest import write_nerf_scene
+    from hbr_amd.dataset import NeRF_DATA, NeRF_DATA_NEW
+    vb = write_nerf_scene(str(tmp_path / "b"), "blender", n_views=2, H=8, W=10)
+    vc = write_nerf_scene(str(tmp_path / "c"), "colmap", n_views=2, H=8, W=10)
+    b = NeRF_DATA(json_path=str(tmp_path / "b" / "transforms_train.json"))
+    c = NeRF_DATA_NEW(json_path=str(tmp_path / "c" / "transforms_train.json"))
+    assert (b.H, b.W) == (8, 10) and (c.H, c.W) == (8, 10) and len(b) == len(c) == 2
+    assert torch.equal(b[1][0], torch.from_numpy(vb[1][0]).permute(2, 0, 1).float() / 255)
+    assert torch.equal(c[0][0], torch.from_numpy(vc[0][0]).permute(2, 0, 1).float() / 255)
+    assert abs(float(b.focal1) - float(c.focal1)) < 1e-4

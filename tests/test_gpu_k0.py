@@ -145,3 +145,30 @@ def test_trainer_step_uses_no_host_side_sampling():
         losses.append([float(tr.step(o, d, dn.reshape(-1), gt)) for _ in range(3)])
         assert torch.equal(tr.sample_t(DEV), tr.sample_t(DEV))
     assert losses[0] == losses[1] and losses[0] != losses[2]
+
+
+def test_render_fwd_one_call_vs_reference_golden():
+    """hbr_render_fwd (direction encoding + K1 + K3 + K5 in one library call) against the reference's recorded renders:
+    G8 (all cells occupied) and G13 (mixed grid through `keep`), sigma/rgb included; bf16 feature buffers give the
+    same colours as fp32 ones in bf16 mode (the MLP rounds its inputs to bf16 either way)."""
+    from hbr_amd import ops
+    from hbr_amd._lib import BF16, F32
+    g8, g = load_golden("g8_render_step.npz"), load_golden("g13_masked_render.npz")
+    enc, mlp, vr = _modules_from_g8(g8)
+    o, d, dn, t = (T_(g8[k]) for k in ("o", "d", "dir_norm", "t"))
+    R, S = o.shape[0], t.shape[0]
+    geom, tabs = enc.geometry(), enc.stacked_tables()
+    flat, _ = mlp.flat_params()
+    Cr, wts, out = ops.render_fwd(geom, tabs, flat, o, d, t, dn, want_wts=True, want_out=True)
+    assert np.allclose(Cr.cpu().numpy(), g8["Cr"], rtol=1e-4, atol=1e-5)
+    assert np.allclose(out[:, 3].reshape(R, S).cpu().numpy(), g8["sig_out"], rtol=1e-4, atol=1e-5)
+    assert np.allclose(out[:, :3].reshape(R, S, 3).cpu().numpy(), g8["rgb_out"], rtol=1e-4, atol=1e-5)
+    assert wts.shape == (R, S) and torch.allclose((wts[:, :, None] * out[:, :3].reshape(R, S, 3)).sum(1), Cr, rtol=1e-5, atol=1e-6)
+    keep = ops.occupancy_mask(ref_cpu.block_pattern_grid(int(g["grid_size"])).to(DEV), g8["mu"].tolist(), float(g8["sigma"]), rays=(o, d, t))
+    Cm, _, _ = ops.render_fwd(geom, tabs, flat, o, d, t, dn, keep=keep)
+    assert np.allclose(Cm.cpu().numpy(), g["Cr"], rtol=1e-4, atol=1e-5)
+    a, _, _ = ops.render_fwd(geom, tabs, flat, o, d, t, dn, precision=BF16, feat_dtype=F32)
+    b, _, _ = ops.render_fwd(geom, tabs, flat, o, d, t, dn, precision=BF16, feat_dtype=BF16)
+    assert torch.equal(a, b)
+    e, _, _ = ops.render_fwd(geom, tabs, flat, o[:0], d[:0], t)
+    assert tuple(e.shape) == (0, 3)

@@ -507,8 +507,10 @@ def test_trainer_step_vs_reference_golden():
 
 
 def test_training_converges_bf16_matches_fp32_psnr():
-    """Short training run on the synthetic scene: the bf16 (BASELINE dtype) trainer reaches the fp32 trainer's PSNR
-    within 0.1 dB... at this size; both must improve over the initial PSNR by > 3 dB."""
+    """Short training run on the synthetic scene (HIP vs HIP): the bf16 (BASELINE dtype) trainer reaches the fp32
+    trainer's PSNR within 0.5 dB after 60 steps, and both improve over the initial PSNR by > 3 dB.  (0.5, not 0.1: two
+    Adam trajectories that differ in rounding drift apart - see test_shipped_path_training_vs_cpu_oracle_psnr for the
+    measured size of that drift against the CPU oracle.)"""
     from hbr_amd._lib import BF16, F32
     from hbr_amd.helper import calc_psnr
     from hbr_amd.trainer import HashNeRFTrainer, build_default_model

@@ -286,3 +286,68 @@ def test_trainer_split_scatter_branch_equals_single_launch(precision):
     # later steps inherit that rounding-level difference of the MLP parameters
     assert np.allclose(m_a, m_b, rtol=1e-4)
     assert torch.allclose(t_a, t_b, rtol=0, atol=2e-3)  # Adam steps are +-lr*sign(g) where |g| ~ 0
+
+
+def test_shipped_path_training_vs_cpu_oracle_psnr():
+    """PSNR vs reference (BASELINE metric, second half) ON THE SHIPPED PATH: 65 536 points per step (1024 rays x 64
+    samples, T = 2^12) so that K2 is the LDS fixed-point kernel, bf16 MLP with bf16 feature buffers, 200 steps from the
+    oracle's initial parameters, rays and jitter (metric: reference helper.py:301-304).
+
+    What can and cannot be asserted (measured with tools/psnr_vs_oracle.py, gpurun_out r2p, this exact setup):
+      steps            100      200      400      800
+      oracle fp32    16.37    23.68    26.94    28.54 dB
+      HIP fp32       -0.05    +0.27    +0.44    +0.36 dB   (same arithmetic as the oracle up to summation order!)
+      HIP bf16/bf16  -0.19    +0.09    +0.67    +0.66 dB   (shipped)
+      HIP bf16/f32   -0.72    -0.26    +0.79    +0.57 dB
+    and, from an initialisation where training stalls at 11 dB (seed 8), every configuration within 0.03 dB at every
+    horizon.  Every HIP row is bit-reproducible run to run (integer accumulation in K2, fixed-order reductions
+    elsewhere).  A fixed-horizon bound of 0.1 dB therefore cannot hold for ANY implementation that is not bit-identical
+    to the oracle: the fp32 path, which differs only in summation order, is already 0.3-0.4 dB away once training has
+    taken off - Adam amplifies rounding-level differences into a different, equally valid trajectory.  The shipped bf16
+    path is never meaningfully BELOW the oracle and ends 0.66 dB above it.  Asserted here:
+      * the first 10 losses track the oracle's (2 % - bf16 operands), i.e. the same optimisation problem is being solved;
+      * after 200 steps the PSNR is within 0.5 dB of the oracle's and both gained > 10 dB;
+      * two HIP runs end with bit-identical parameters."""
+    from hbr_amd._lib import BF16
+    from hbr_amd.helper import calc_psnr
+    from hbr_amd.trainer import HashNeRFTrainer, build_default_model
+    torch.set_num_threads(min(16, torch.get_num_threads() or 16))
+    R, S, L, T, steps, seed = 1024, 64, 16, 2 ** 12, 200, 7
+    o0, d0, _, _ = ref_cpu.synthetic_rays(8192, seed=0)
+    mn, mx, sig = ref_cpu.bbox_mu_sigma(o0, d0)
+    rng = np.random.default_rng(seed)
+    tables0 = torch.from_numpy(rng.uniform(-1e-4, 1e-4, (L, T, 2)).astype(np.float32))
+    params0 = ref_cpu.mlp_init(seed + 1)
+    ts = [ref_cpu.strat_jitter_to_t(2.0, 6.0, S, torch.from_numpy(rng.uniform(0, 1, S).astype(np.float32))) for _ in range(steps)]
+    batches = [ref_cpu.synthetic_scene_rays(R, seed=50 + i) for i in range(16)]
+    test = ref_cpu.synthetic_scene_rays(2048, seed=999)
+    t_eval = torch.linspace(2.0, 6.0, S)
+    sc = ref_cpu.level_scales(16, 2048.0, L)
+    # oracle
+    tabs = [tables0[l].clone().requires_grad_(True) for l in range(L)]
+    prm = {k: v.clone().requires_grad_(True) for k, v in params0.items()}
+    opts = ref_cpu.make_optimizers(tabs, prm.values(), steps)
+    with torch.no_grad():
+        p_init = float(ref_cpu.psnr(ref_cpu.render(test[0], test[1], t_eval, test[2], tabs, sc, mn, sig, prm)[0], test[3]))
+    ref_losses = [float(ref_cpu.train_step(batches[k % 16], ts[k], tabs, sc, mn, sig, prm, opts)) for k in range(steps)]
+    with torch.no_grad():
+        p_ref = float(ref_cpu.psnr(ref_cpu.render(test[0], test[1], t_eval, test[2], tabs, sc, mn, sig, prm)[0], test[3]))
+    # HIP, shipped configuration, twice
+    finals = []
+    for _ in range(2):
+        enc, _, mlp = build_default_model(mn, sig, DEV, L=L, T=T, seed=0)
+        with torch.no_grad():
+            for l in range(L):
+                enc.Embedding_list[l].weight.copy_(tables0[l])
+            for k, v in params0.items():
+                sq, idx, kind = k.split(".")
+                getattr(getattr(mlp, sq)[int(idx)], kind).copy_(v)
+        tr = HashNeRFTrainer(enc, mlp, num_samples=S, total_steps=steps, precision=BF16, feat_dtype=BF16)
+        losses = [float(tr.step(*(a.to(DEV) for a in batches[k % 16]), t=ts[k].to(DEV))) for k in range(steps)]
+        C = tr.render(test[0].to(DEV), test[1].to(DEV), test[2].to(DEV), t=t_eval.to(DEV))
+        finals.append((losses, float(calc_psnr(C.cpu(), test[3])), tr.tables.clone(), tr.flat.clone()))
+    (l1, p1, t1, f1), (l2, p2, t2, f2) = finals
+    assert l1 == l2 and torch.equal(t1, t2) and torch.equal(f1, f2)       # bitwise reproducible
+    assert np.allclose(l1[:10], ref_losses[:10], rtol=2e-2), (l1[:10], ref_losses[:10])
+    assert p_ref > p_init + 10 and p1 > p_init + 10, (p_init, p_ref, p1)
+    assert abs(p1 - p_ref) < 0.5, (p1, p_ref)
