@@ -266,10 +266,15 @@ __global__ __launch_bounds__(256) void absmax_kernel(const void* __restrict__ dy
 
 // one workgroup: partial maxima / boxes -> Meta.  `given` (optional): per-level maxima handed in by the caller.
 // Wave w reduces the maxima of levels w, w + 16 (no workgroup barrier); then all threads reduce the boxes.
+// Ray mode with few rays (`direct_rays` > 0): the boxes of the rays' end points are taken right here instead of by a
+// bounds_kernel launch (only below 4096 rays: each box costs six IEEE divisions, and at 16 000 rays one workgroup
+// doing them took 20 us against 8 + 6 us for the two launches).
 __global__ __launch_bounds__(1024) void meta_reduce_kernel(const uint32_t* __restrict__ abs_part, int abs_blocks,
                                                            const float* __restrict__ given, const float* __restrict__ bounds_part,
-                                                           uint32_t nboxes, int L, Meta* __restrict__ meta) {
+                                                           uint32_t nboxes, int L, Meta* __restrict__ meta, PointSrc ps, HashGeom g,
+                                                           uint32_t direct_rays) {
   __shared__ float red[16][7];
+  __shared__ float trange[3];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (int l = wv; l < HBR_MAX_LEVELS; l += 16) {
     uint32_t m = 0;
@@ -283,13 +288,46 @@ __global__ __launch_bounds__(1024) void meta_reduce_kernel(const uint32_t* __res
   }
   const float inf = __uint_as_float(0x7f800000u);
   float v[7] = {inf, inf, inf, -inf, -inf, -inf, 1.f};
-  for (uint32_t s = threadIdx.x; s < nboxes; s += 1024) {
-    const float* p = bounds_part + (size_t)s * 7;
+  if (direct_rays) {
+    float lo = inf, hi = -inf, ok = 1.f;
+    for (uint32_t s = threadIdx.x; s < ps.S; s += 1024) {
+      const float tt = ps.t[s];
+      lo = fminf(lo, tt); hi = fmaxf(hi, tt);
+      if (!isfinite(tt)) ok = 0.f;
+    }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) v[k] = fminf(v[k], p[k]);
+    for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); ok = fminf(ok, __shfl_xor(ok, o)); }
+    if (lane == 0) { red[wv][0] = lo; red[wv][1] = hi; red[wv][2] = ok; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 16; ++w) { lo = fminf(lo, red[w][0]); hi = fmaxf(hi, red[w][1]); ok = fminf(ok, red[w][2]); }
+      trange[0] = lo; trange[1] = hi; trange[2] = ok;
+    }
+    __syncthreads();
+    v[6] = trange[2];
+    for (uint32_t r = threadIdx.x; r < direct_rays; r += 1024) {
+      const float* o = ps.o + (size_t)r * 3;
+      const float* d = ps.d + (size_t)r * 3;
 #pragma unroll
-    for (int k = 3; k < 6; ++k) v[k] = fmaxf(v[k], p[k]);
-    v[6] = fminf(v[6], p[6]);
+      for (int e = 0; e < 2; ++e) {
+        const float tt = trange[e];
+        float nx, ny, nz;
+        normalise(g, __fadd_rn(o[0], __fmul_rn(d[0], tt)), __fadd_rn(o[1], __fmul_rn(d[1], tt)), __fadd_rn(o[2], __fmul_rn(d[2], tt)), nx, ny, nz);
+        v[0] = fminf(v[0], nx); v[1] = fminf(v[1], ny); v[2] = fminf(v[2], nz);
+        v[3] = fmaxf(v[3], nx); v[4] = fmaxf(v[4], ny); v[5] = fmaxf(v[5], nz);
+        if (!(isfinite(nx) && isfinite(ny) && isfinite(nz))) v[6] = 0.f;
+      }
+    }
+    __syncthreads();  // red is reused below
+  } else {
+    for (uint32_t s = threadIdx.x; s < nboxes; s += 1024) {
+      const float* p = bounds_part + (size_t)s * 7;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) v[k] = fminf(v[k], p[k]);
+#pragma unroll
+      for (int k = 3; k < 6; ++k) v[k] = fmaxf(v[k], p[k]);
+      v[6] = fminf(v[6], p[6]);
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -886,7 +924,8 @@ extern "C" int hbr_hash_encode_bwd(const float* x, const float* rays_o, const fl
   hipLaunchKernelGGL(normalise_kernel, dim3(stripes), dim3(1024), 0, st, ps, N, g, (float*)(wsb + w.xnorm));
   const uint32_t items = ps.x ? N : (uint32_t)R;            // boxes: per point, or per ray (two end points each)
   const uint32_t nboxes = (items + 1023u) / 1024u;          // <= stripes
-  hipLaunchKernelGGL(bounds_kernel, dim3(nboxes), dim3(1024), 0, st, ps, items, g, (float*)(wsb + w.bounds_part));
+  const uint32_t direct_rays = (!ps.x && R <= 4096) ? (uint32_t)R : 0u;  // few rays: meta_reduce_kernel takes their boxes itself
+  if (!direct_rays) hipLaunchKernelGGL(bounds_kernel, dim3(nboxes), dim3(1024), 0, st, ps, items, g, (float*)(wsb + w.bounds_part));
   uint32_t* abs_part = (uint32_t*)(wsb + w.abs_part);
   int abs_blocks = 0;
   if (!dy_absmax) {
@@ -899,7 +938,7 @@ extern "C" int hbr_hash_encode_bwd(const float* x, const float* rays_o, const fl
     }
   }
   hipLaunchKernelGGL(meta_reduce_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)abs_part, abs_blocks, dy_absmax,
-                     (const float*)(wsb + w.bounds_part), nboxes, L, (Meta*)(wsb + w.meta));
+                     (const float*)(wsb + w.bounds_part), nboxes, L, (Meta*)(wsb + w.meta), ps, g, direct_rays);
 #define HBR_BWD(P, LY, DT) rc = launch_lds<P, LY, DT>(st, N, dy, dy_stride, g, dtables, wsb, w, full)
   if (g.pow2) {
     if (layout == HBR_LAYOUT_PLANAR) { if (dy_dtype == HBR_F32) HBR_BWD(true, HBR_LAYOUT_PLANAR, HBR_F32); else HBR_BWD(true, HBR_LAYOUT_PLANAR, HBR_BF16); }

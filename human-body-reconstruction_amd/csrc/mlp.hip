@@ -533,72 +533,83 @@ static_assert(kSlabWg % 32 == 0, "reduce kernel takes 32 entries per block");
 constexpr int kMaxBwdBlocks = 256;                 // one workgroup per CU
 __device__ __host__ constexpr int64_t slab_offset_bytes(int64_t img_bytes) { return (img_bytes + 255) / 256 * 256; }
 
-// 256 threads = 32 consecutive slab entries x 8 parts; part p sums slabs p, p+8, ... with four loads in flight, the
-// eight partials are combined through LDS in a fixed order (a single thread per entry walking all 256 slabs was
-// latency-bound: 62 us).  Several slab entries can stand for the same parameter - the two waves that share a tile of a
-// two-tile layer, and the 4 waves x 2 lane halves that hold partial sums of one bias row - so ONE of them (the
-// "leader": the even wave / wave 0's lower half) also walks its siblings, in a fixed order, and the others return:
-// every parameter has exactly one writer and one summation order, i.e. the MLP gradient is bitwise reproducible.
-__global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(const float* __restrict__ slabs, int nblocks,
-                                                            float* __restrict__ dparams, const uint32_t* __restrict__ abs_part,
-                                                            float* __restrict__ absmax_out) {
-  __shared__ float part[8][32];
-  if (blockIdx.x == kSlabWg / 32) {  // the extra block: per-level max |d feat| over the waves' partials -> absmax_out[16]
-    const int level = threadIdx.x >> 4, sub = threadIdx.x & 15;
-    uint32_t m = 0;
-    for (int w = sub; w < nblocks * 4; w += 16) m = max(m, abs_part[(size_t)level * kAbsWaves + w]);
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
-    if (sub == 0) absmax_out[level] = __uint_as_float(m);
-    return;
-  }
-  const int el = threadIdx.x & 31, p = threadIdx.x >> 5;
-  const int e = blockIdx.x * 32 + el;  // (wave, register, lane) of the slab layout; kSlabWg is a multiple of 32
-  // where this slab entry belongs in the flat parameter block (-1: a padding row/column of its tile, or a sibling
-  // that its leader sums - never read here)
+// flat-parameter offset of slab entry e = (wave, register, lane), or -1 for a padding row/column of its tile
+__device__ __forceinline__ int slab_entry_offset(int e) {
   const int lane = e & 63, r = (e >> 6) % kSlabRegs, wv = e / kSlabWave, h = lane >> 5;
-  int off, nsib = 1, sib_stride = 0;  // siblings: entries e + k * sib_stride (+ 32 for the upper lane half of a bias)
-  bool bias = false;
   if (r < NLAYER * 16) {
     const int l = r >> 4, q = r & 15;
     const int nout = (l == L3 || l == C3) ? 1 : 2;
     const int tiles = ((l == L1) ? 1 : 2) * nout;
     const int tau = (tiles == 4) ? wv : (wv >> 1);
-    const int nin_t = tau / nout, mout_t = tau % nout;
-    off = wlog_offset(l, 32 * mout_t + (lane & 31), 32 * nin_t + acc_row(q, h));
+    return wlog_offset(l, 32 * (tau % nout) + (lane & 31), 32 * (tau / nout) + acc_row(q, h));
+  }
+  const int i = r - NLAYER * 16;  // bias partial i: layer l, out tile m (db_base)
+  int l = NLAYER - 1;
+  while (db_base(l) > i) --l;
+  return blog_offset(l, 32 * (i - db_base(l)) + (lane & 31));
+}
+
+// Stage 1: 256 threads = 32 consecutive slab entries x 8 parts; part p sums slabs p, p+8, ... with four loads in
+// flight, the eight partials are combined through LDS in a fixed order (a single thread per entry walking all 256
+// slabs was latency-bound: 62 us) -> tot[entry].  Sixteen extra blocks reduce the per-wave feature-gradient maxima.
+__global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(const float* __restrict__ slabs, int nblocks, float* __restrict__ tot,
+                                                            const uint32_t* __restrict__ abs_part, float* __restrict__ absmax_out) {
+  __shared__ float part[8][32];
+  if (blockIdx.x >= kSlabWg / 32) {  // 16 extra blocks, one per level: max |d feat| over the waves' partials -> absmax_out[level]
+    __shared__ uint32_t wmax[4];
+    const int level = blockIdx.x - kSlabWg / 32;
+    uint32_t m = 0;
+    for (int w = threadIdx.x; w < nblocks * 4; w += 256) m = max(m, abs_part[(size_t)level * kAbsWaves + w]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) absmax_out[level] = __uint_as_float(max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
+    return;
+  }
+  const int el = threadIdx.x & 31, p = threadIdx.x >> 5;
+  const float* src = slabs + blockIdx.x * 32 + el;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (slab_entry_offset(blockIdx.x * 32 + el) >= 0) {  // padding entries (over half of the slab) are never read
+    int b = p;
+    for (; b + 24 < nblocks; b += 32) {
+      a0 += src[(size_t)b * kSlabWg];
+      a1 += src[(size_t)(b + 8) * kSlabWg];
+      a2 += src[(size_t)(b + 16) * kSlabWg];
+      a3 += src[(size_t)(b + 24) * kSlabWg];
+    }
+    for (; b < nblocks; b += 8) a0 += src[(size_t)b * kSlabWg];
+  }
+  part[p][el] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (p != 0) return;
+  tot[blockIdx.x * 32 + el] = ((part[0][el] + part[1][el]) + (part[2][el] + part[3][el])) + ((part[4][el] + part[5][el]) + (part[6][el] + part[7][el]));
+}
+
+// Stage 2: slab entries -> parameters.  Several entries can stand for the same parameter - the two waves that share
+// a tile of a two-tile layer, and the 4 waves x 2 lane halves that hold partial sums of one bias row - so ONE of them
+// (the "leader": the even wave / wave 0's lower half) adds up its siblings in a fixed order and the others return:
+// every parameter has exactly one writer and one summation order, i.e. the MLP gradient is bitwise reproducible.
+__global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(const float* __restrict__ tot, float* __restrict__ dparams) {
+  const int e = blockIdx.x * 256 + threadIdx.x;  // (wave, register, lane) of the slab layout
+  if (e >= kSlabWg) return;
+  const int lane = e & 63, r = (e >> 6) % kSlabRegs, wv = e / kSlabWave, h = lane >> 5;
+  const int off = slab_entry_offset(e);
+  if (off < 0) return;
+  float v = tot[e];
+  if (r < NLAYER * 16) {
+    const int l = r >> 4;
+    const int tiles = ((l == L1) ? 1 : 2) * ((l == L3 || l == C3) ? 1 : 2);
     if (tiles != 4) {
-      if (wv & 1) off = -1;
-      nsib = 2; sib_stride = kSlabWave;
+      if (wv & 1) return;
+      v += tot[e + kSlabWave];
     }
   } else {
-    const int i = r - NLAYER * 16;  // bias partial i: layer l, out tile m (db_base)
-    int l = NLAYER - 1;
-    while (db_base(l) > i) --l;
-    off = (wv == 0 && h == 0) ? blog_offset(l, 32 * (i - db_base(l)) + (lane & 31)) : -1;
-    bias = true; nsib = 4; sib_stride = kSlabWave;
+    if (wv != 0 || h != 0) return;
+    v += tot[e + 32];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) v += tot[e + k * kSlabWave] + tot[e + k * kSlabWave + 32];
   }
-  float tot = 0.f;
-  if (off >= 0) {
-    for (int k = 0; k < nsib; ++k) {
-      for (int hh = 0; hh < (bias ? 2 : 1); ++hh) {
-        const float* src = slabs + e + k * sib_stride + 32 * hh;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int b = p;
-        for (; b + 24 < nblocks; b += 32) {
-          a0 += src[(size_t)b * kSlabWg];
-          a1 += src[(size_t)(b + 8) * kSlabWg];
-          a2 += src[(size_t)(b + 16) * kSlabWg];
-          a3 += src[(size_t)(b + 24) * kSlabWg];
-        }
-        for (; b < nblocks; b += 8) a0 += src[(size_t)b * kSlabWg];
-        tot += (a0 + a1) + (a2 + a3);
-      }
-    }
-  }
-  part[p][el] = tot;
-  __syncthreads();
-  if (p != 0 || off < 0) return;
-  const float v = ((part[0][el] + part[1][el]) + (part[2][el] + part[3][el])) + ((part[4][el] + part[5][el]) + (part[6][el] + part[7][el]));
   dparams[off] += v;  // the only writer of this address
 }
 
@@ -1034,8 +1045,10 @@ static int launch_bwd_fused(uint32_t ntiles, hipStream_t st, const char* img, Fe
   dfd.abs_part = want_abs ? (uint32_t*)(slabs + (size_t)kMaxBwdBlocks * kSlabWg) : nullptr;  // behind the slabs
   int rc = launch_with_lds(mlp_bwd_fused_kernel<P, LAYOUT, DT, WLDS>, dim3(blocks), dim3(256), lds, st, img, fs, ps, dout, dfd, slabs);
   if (rc) return rc;
-  hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(kSlabWg / 32 + (want_abs ? 1 : 0)), dim3(256), 0, st, (const float*)slabs, (int)blocks,
-                     dparams, (const uint32_t*)dfd.abs_part, absmax_out);
+  float* tot = slabs + (size_t)kMaxBwdBlocks * kSlabWg + 16 * (size_t)kAbsWaves;  // behind the maxima
+  hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(kSlabWg / 32 + (want_abs ? 16 : 0)), dim3(256), 0, st, (const float*)slabs, (int)blocks,
+                     tot, (const uint32_t*)dfd.abs_part, absmax_out);
+  hipLaunchKernelGGL(mlp_dw_finalize_kernel, dim3((kSlabWg + 255) / 256), dim3(256), 0, st, (const float*)tot, dparams);
   return HBR_OK;
 }
 
@@ -1069,7 +1082,7 @@ using namespace hbr::mlp;
 extern "C" int64_t hbr_mlp_workspace_bytes(int precision) {
   // the MFMA-fragment image of the weights, then (backward only) one weight-gradient slab per workgroup
   const int64_t img = precision == HBR_BF16 ? Tab<PBf16>::IMG_BYTES : Tab<PF32>::IMG_BYTES;
-  return slab_offset_bytes(img) + (int64_t)kMaxBwdBlocks * kSlabWg * (int64_t)sizeof(float) + 16 * (int64_t)kAbsWaves * 4;
+  return slab_offset_bytes(img) + ((int64_t)kMaxBwdBlocks * kSlabWg + 16 * (int64_t)kAbsWaves + kSlabWg) * (int64_t)sizeof(float);
 }
 
 extern "C" int hbr_dir_encode(const float* x, int64_t rows, int d_model, int num_freq, float* out, void* stream) {

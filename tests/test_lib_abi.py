@@ -33,8 +33,8 @@ def test_header_symbols_all_exported(L):
     # slab per backward workgroup: 256 workgroups x 4 waves x (6 tiles x 16 + 10 bias) registers x 64 lanes x 4 B
     img = (34 + 28) * 1024 + 6 * 64 * 4
     assert img % 256 == 0
-    # ... and the per-wave feature-gradient maxima of the backward: 16 levels x 1024 waves x 4 B
-    slabs = 256 * 4 * (6 * 16 + 10) * 64 * 4 + 16 * 1024 * 4
+    # ... the per-wave feature-gradient maxima of the backward (16 levels x 1024 waves x 4 B) and one slab of totals
+    slabs = 256 * 4 * (6 * 16 + 10) * 64 * 4 + 16 * 1024 * 4 + 4 * (6 * 16 + 10) * 64 * 4
     assert lib.hbr_mlp_workspace_bytes(L.BF16) == img + slabs
     img32 = (264 + 216) * 256 + 6 * 64 * 4
     assert lib.hbr_mlp_workspace_bytes(L.F32) == (img32 + 255) // 256 * 256 + slabs

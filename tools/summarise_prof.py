@@ -9,7 +9,12 @@ tag = sys.argv[1]
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
-KERNELS = {"hash_fwd": "hash_fwd_kernel", "hash_bwd": "hash_bwd_lds_kernel", "mlp_fwd": "mlp_fwd_kernel", "mlp_bwd": "mlp_bwd_fused_kernel"}
+# bench.py's four timed spans -> the kernels each one launches (K2 and K4 are short sequences of kernels; a span's HBM
+# traffic is the sum over its kernels, one launch of each per step)
+KERNELS = {"hash_fwd": ["hash_fwd_kernel"],
+           "hash_bwd": ["normalise_kernel", "bounds_kernel", "absmax_", "meta_reduce_kernel", "hash_scatter_kernel", "dense_scatter_kernel",
+                        "slab_reduce_kernel"],
+           "mlp_fwd": ["mlp_fwd_kernel"], "mlp_bwd": ["mlp_bwd_fused_kernel", "mlp_dw_reduce_kernel"]}
 
 stats = glob.glob(os.path.join(src, "kt", "**", "*kernel_stats.csv"), recursive=True)[0]
 rows = list(csv.reader(open(stats)))
@@ -21,22 +26,30 @@ with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
             w.writerow(r)
 
 def counter(name):
+    """span -> kernel pattern -> list of per-launch counter values"""
     f = glob.glob(os.path.join(src, name, "**", "*counter_collection.csv"), recursive=True)[0]
-    acc = defaultdict(list)
+    acc = defaultdict(lambda: defaultdict(list))
     for r in csv.DictReader(open(f)):
-        for k, pat in KERNELS.items():
-            if pat in r["Kernel_Name"]:
-                acc[k].append(float(r["Counter_Value"]))
+        for k, pats in KERNELS.items():
+            for pat in pats:
+                if pat in r["Kernel_Name"]:
+                    acc[k][pat].append(float(r["Counter_Value"]))
     return acc
 
 fetch, write = counter("fetch"), counter("write")
 traffic = {}
 with open(os.path.join(dst, f"{tag}_pmc_hbm.csv"), "w") as f:
-    f.write("kernel,launches,FETCH_SIZE_KiB_avg,WRITE_SIZE_KiB_avg,hbm_bytes_per_launch=(FETCHx2+WRITE)*1024\n")
-    for k in KERNELS:
-        fa, wa = sum(fetch[k]) / len(fetch[k]), sum(write[k]) / len(write[k])
-        traffic[k] = (2 * fa + wa) * 1024
-        f.write(f"{k},{len(fetch[k])},{fa:.1f},{wa:.1f},{traffic[k]:.0f}\n")
+    f.write("span,kernel,launches,FETCH_SIZE_KiB_avg,WRITE_SIZE_KiB_avg,hbm_bytes_per_launch=(FETCHx2+WRITE)*1024\n")
+    for k, pats in KERNELS.items():
+        tot = 0.0
+        for pat in pats:
+            if not fetch[k][pat]:
+                continue
+            fa, wa = sum(fetch[k][pat]) / len(fetch[k][pat]), sum(write[k][pat]) / len(write[k][pat])
+            tot += (2 * fa + wa) * 1024
+            f.write(f"{k},{pat},{len(fetch[k][pat])},{fa:.1f},{wa:.1f},{(2 * fa + wa) * 1024:.0f}\n")
+        traffic[k] = tot
+        f.write(f"{k},TOTAL,,,,{tot:.0f}\n")
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 line = [l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")][-1]
 # the bench line was printed before this round's PMC passes existed: its `traffic` fields (read from the previous
