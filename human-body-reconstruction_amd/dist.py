@@ -50,6 +50,21 @@ def allreduce_mean_(flat: torch.Tensor, world: int, group=None, scale_in_place: 
     return flat
 
 
+def allreduce_mean_grads_(grads, world: int, group=None) -> None:
+    """Average a list of gradient tensors over the ranks with ONE all-reduce: they are packed into a single flat
+    buffer (8.05 MiB for the 16 tables + 12 MLP tensors), reduced, and copied back - not one collective per tensor."""
+    if world <= 1 or not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.mul_(1.0 / world)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+
+
 class StagedAllReduce:
     """The step's gradient all-reduce issued in pieces, each as soon as its slice of the flat buffer is final, so that
     all but the last piece overlap the kernels still producing the rest (RCCL runs them on its own stream; `launch`

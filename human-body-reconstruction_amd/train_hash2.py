@@ -134,9 +134,8 @@ def main(argv=None):
                                               dir_norm=batch[2], hierarchical=True)
                     loss = crit(Cr, batch[3]) + crit(Cf, batch[3])
                 loss.backward()
-                if world > 1:
-                    for p in list(enc.Embedding_list.parameters()) + list(nerf.parameters()):
-                        hdist.allreduce_mean_(p.grad, world)
+                if world > 1:  # ONE collective over all 28 gradients, as the fused trainer's flat buffer gets
+                    hdist.allreduce_mean_grads_([p.grad for p in list(enc.Embedding_list.parameters()) + list(nerf.parameters())], world)
                 oe.step(); om.step(); se.step(); sm.step()
                 om.zero_grad(set_to_none=True); oe.zero_grad(set_to_none=True)
             else:

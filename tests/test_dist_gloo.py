@@ -67,8 +67,12 @@ def _worker(rank, world, port, out_dir):
         red.launch(piece)
     red.finish()
     staged.mul_(1.0 / world)
+    # ... and the list form the --hierarchical route uses (28 tensors packed into one collective)
+    pieces = [flat[:cut].clone(), flat[cut:nt].clone().view(-1, 2), flat[nt:].clone()]
+    hd.allreduce_mean_grads_(pieces, world)
     hd.allreduce_mean_(flat, world)
     assert torch.equal(staged, flat)
+    assert torch.equal(torch.cat([p.reshape(-1) for p in pieces]), flat)
     torch.save(flat, os.path.join(out_dir, f"g{rank}.pt"))
     torch.distributed.destroy_process_group()
 
