@@ -268,42 +268,71 @@ __device__ __forceinline__ void dense(const char* img, int fbase, const float* b
   }
 }
 
+// Packed 16-bit helpers on bf16 pairs (one VGPR = two activations).  Inline asm: hipcc 7.2 scalarises 8-wide `short`
+// vectors and miscompiled the element-wise update of a bit-cast vector in a loop (round 1), and for `fmaxf(x, 0)` it
+// emits a canonicalising `v_max_f32 x, x, x` in front of the max - 2 instructions per activation, 256 per tile.
+//   ReLU of a bf16 = signed 16-bit max with 0 (negative floats are negative integers; -0 -> +0).
+//   "was the ReLU output positive" = its bits are non-zero: min(bits, 1) is 0 / 1, and a 16-bit multiply by it keeps
+//   or clears a gradient's bits.
+__device__ __forceinline__ uint32_t pk_relu_bf16(uint32_t w) {
+  uint32_t r;
+  asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(w));
+  return r;
+}
+__device__ __forceinline__ uint32_t pk_keep_where_nonzero(uint32_t grad, uint32_t act, uint32_t ones /* 0x00010001 */) {
+  uint32_t m, r;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(act), "v"(ones));
+  asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(grad), "v"(m));
+  return r;
+}
+
 // ReLU + re-pack.  No mask is recorded: the backward pass reads the sign back from the packed activations themselves
-// (a ReLU output is > 0 exactly where its bits are non-zero), which saves three VALU ops per element in the forward.
+// (a ReLU output is > 0 exactly where its bits are non-zero).  bf16: round first, then one packed integer max per PAIR
+// (rounding is monotonic and keeps the sign, so relu(round(x)) == round(relu(x))); f32: an integer max on the bits.
 template <class P, int NT>
 __device__ __forceinline__ void relu_frags(f32x16 (&acc)[NT], typename P::frag (&out)[NT * P::S32]) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
+    if constexpr (P::ELEMS == 8) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[t][q] = fmaxf(acc[t][q], 0.f);
+      for (int s = 0; s < P::S32; ++s) {
+        u32x4 w = __builtin_bit_cast(u32x4, P::from_acc(acc[t], s));
 #pragma unroll
-    for (int s = 0; s < P::S32; ++s) out[t * P::S32 + s] = P::from_acc(acc[t], s);
+        for (int k = 0; k < 4; ++k) w[k] = pk_relu_bf16(w[k]);
+        out[t * P::S32 + s] = __builtin_bit_cast(bf16x8, w);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[t][q] = __int_as_float(max(__float_as_int(acc[t][q]), 0));
+#pragma unroll
+      for (int s = 0; s < P::S32; ++s) out[t * P::S32 + s] = P::from_acc(acc[t], s);
+    }
   }
 }
 
-// dZ = dX where the forward activation h was positive, else 0; then re-pack
+// dZ = dX where the forward activation h was positive, else 0; then re-pack (bf16: re-pack first, mask the pairs)
 template <class P, int NT>
 __device__ __forceinline__ void mask_frags(f32x16 (&acc)[NT], const typename P::frag (&h)[NT * P::S32],
                                            typename P::frag (&out)[NT * P::S32]) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
+    if constexpr (P::ELEMS == 8) {
+      uint32_t ones = 0x00010001u;
+      asm volatile("" : "+v"(ones));  // keep it in one VGPR (the asm operands below are VGPR-only)
 #pragma unroll
-    for (int s = 0; s < P::S32; ++s) {
-      if constexpr (P::ELEMS == 8) {
-        // a ReLU output is positive exactly where its bf16 bits are non-zero; test the packed pairs directly
-        // (a per-element __builtin_bit_cast<uint16_t>(h[..][j]) test gave wrong masks with hipcc 7.2 - keep the u32 form)
+      for (int s = 0; s < P::S32; ++s) {
+        u32x4 w = __builtin_bit_cast(u32x4, P::from_acc(acc[t], s));
         const u32x4 hw = __builtin_bit_cast(u32x4, h[t * P::S32 + s]);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          acc[t][8 * s + 2 * k] = (hw[k] & 0xffffu) ? acc[t][8 * s + 2 * k] : 0.f;
-          acc[t][8 * s + 2 * k + 1] = (hw[k] > 0xffffu) ? acc[t][8 * s + 2 * k + 1] : 0.f;
-        }
-      } else {
-        acc[t][s] = (h[t * P::S32 + s] > 0.f) ? acc[t][s] : 0.f;
+        for (int k = 0; k < 4; ++k) w[k] = pk_keep_where_nonzero(w[k], hw[k], ones);
+        out[t * P::S32 + s] = __builtin_bit_cast(bf16x8, w);
       }
-    }
+    } else {
 #pragma unroll
-    for (int s = 0; s < P::S32; ++s) out[t * P::S32 + s] = P::from_acc(acc[t], s);
+      for (int s = 0; s < P::S32; ++s) acc[t][s] = (h[t * P::S32 + s] > 0.f) ? acc[t][s] : 0.f;
+#pragma unroll
+      for (int s = 0; s < P::S32; ++s) out[t * P::S32 + s] = P::from_acc(acc[t], s);
+    }
   }
 }
 
