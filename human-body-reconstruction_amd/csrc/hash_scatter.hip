@@ -445,6 +445,7 @@ __device__ __forceinline__ void hashed_slice_body(const uint32_t b, unsigned lon
   // weight products - was measured SLOWER, 610 vs 589 us: a packed instruction issues at half rate here.)
   auto visit = [&](auto nonneg_tag, float nx, float ny, float nz, float dv) {
     constexpr bool NONNEG = decltype(nonneg_tag)::value;
+    constexpr bool BOXED = NONNEG;  // the launch's bounding box also proves cx < 16383 (see `nonneg` below)
     const float dvs = __fmul_rn(dv, fs.mul);  // exact: a power of two
     Cell c;
     if constexpr (NONNEG) {
@@ -467,8 +468,9 @@ __device__ __forceinline__ void hashed_slice_body(const uint32_t b, unsigned lon
       // y/z terms it is < kSliceBytes exactly when the row is in the slice, and is then the byte offset inside it.
       const uint32_t mask8 = g.mask << 3, lo8 = row_lo << 3;
       const uint32_t xs = (uint32_t)c.cx << 3;
-      const uint32_t y0 = (uint32_t)c.cy * (kPrimeY << 3), y1 = y0 + (kPrimeY << 3);
-      const uint32_t zz0 = (uint32_t)c.cz * (kPrimeZ << 3), zz1 = zz0 + (kPrimeZ << 3);
+      // (24-bit multiplies - c * P = c * P[23:0] + ((c * P[31:24]) << 24) - instead of v_mul_lo_u32: measured, no difference)
+      const uint32_t y0 = (uint32_t)c.cy * (kPrimeY << 3), zz0 = (uint32_t)c.cz * (kPrimeZ << 3);
+      const uint32_t y1 = y0 + (kPrimeY << 3), zz1 = zz0 + (kPrimeZ << 3);
       const uint32_t a[4] = {(y0 ^ zz0 ^ lo8) & mask8, (y1 ^ zz0 ^ lo8) & mask8, (y0 ^ zz1 ^ lo8) & mask8,
                              (y1 ^ zz1 ^ lo8) & mask8};
       // The x term of the hash is the cell coordinate itself: while 0 <= cx and cx + 1 < kSliceRows it cannot reach the
@@ -476,7 +478,7 @@ __device__ __forceinline__ void hashed_slice_body(const uint32_t b, unsigned lon
       // x-neighbours of a (y, z) pair are in the slice together - four tests per visit instead of eight, and both
       // atomics of a pair run under one exec mask.  Negative cells (points outside the box), coordinates that need
       // N_l * extent > 16384 and tables smaller than a slice take the per-corner form below.
-      if (__all((uint32_t)c.cx < (uint32_t)(kSliceRows - 1)) && g.T >= kSliceRows) {
+      if ((BOXED || __all((uint32_t)c.cx < (uint32_t)(kSliceRows - 1))) && g.T >= kSliceRows) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {  // pair p: y bit = p & 1, z bit = p >> 1 (corner = x + 2 y + 4 z, hash_encoding.py:34-37)
           if (a[p] < kSliceBytes) {
@@ -508,7 +510,10 @@ __device__ __forceinline__ void hashed_slice_body(const uint32_t b, unsigned lon
   // address serialise), the coordinates of a step are one contiguous 768-byte read, and the lane's 16 dy values one
   // contiguous 64 / 128 bytes fetched up front.
   const bool vec_ok = LAYOUT == HBR_LAYOUT_PLANAR && SegDy<DTYPE>::aligned(dy, l, N);
-  const bool nonneg = meta->finite && meta->lo[0] >= 0.f && meta->lo[1] >= 0.f && meta->lo[2] >= 0.f && scale >= 0.f;
+  // From the launch's bounding box (uniform over the workgroup): no coordinate negative and every cell's x below the
+  // slice-select bits -> the visit needs no per-point range check (NONNEG / BOXED above; 0.594 -> 0.587 ms).
+  const bool nonneg = meta->finite && meta->lo[0] >= 0.f && meta->lo[1] >= 0.f && meta->lo[2] >= 0.f && scale >= 0.f &&
+                      __fmul_rn(meta->hi[0], scale) < (float)(kSliceRows - 2);
   auto sweep = [&](auto nonneg_tag) {
     for (uint32_t s = s_begin + wv; s < s_end; s += kLdsBwdThreads / 64) {
       const float* q = xnorm + ((size_t)s * 1024u + lane) * 3;
@@ -875,7 +880,7 @@ using namespace hbr;
 
 extern "C" int64_t hbr_hash_bwd_workspace_bytes(int64_t N, int L, int64_t T, int, int algo) {
   if (algo == 1 || (algo == 0 && N < 65536) || !lds_shape_ok(N, L, T)) return 0;
-  return workspace(N, L, T).total;
+  return workspace(N, L, T).total;  // (the coordinate part depends on N only, so it is shared by calls over level sub-ranges)
 }
 extern "C" int64_t hbr_hash_bwd_workspace_bytes_min(int64_t N, int L, int64_t T, int, int algo) {
   if (algo == 1 || (algo == 0 && N < 65536) || !lds_shape_ok(N, L, T)) return 0;
@@ -891,7 +896,9 @@ extern "C" int hbr_hash_encode_bwd(const float* x, const float* rays_o, const fl
   if (layout != HBR_LAYOUT_ROWS && layout != HBR_LAYOUT_PLANAR) return HBR_EINVAL;
   if (dy_dtype != HBR_F32 && dy_dtype != HBR_BF16) return HBR_EINVAL;
   if (layout == HBR_LAYOUT_ROWS && dy_stride < (int64_t)L * F) return HBR_EINVAL;
-  if (algo < 0 || algo > 2) return HBR_EINVAL;
+  if (algo < 0 || algo > 3) return HBR_EINVAL;
+  const bool reuse_coords = algo == 3;  // algo 3 = algo 2, the coordinates (and their boxes) of the previous call on `ws` still valid
+  if (reuse_coords) algo = 2;
   HashGeom g;
   int rc = fill_geom(g, scales_host, mu_host, sigma, L, T);
   if (rc) return rc;
@@ -921,11 +928,11 @@ extern "C" int hbr_hash_encode_bwd(const float* x, const float* rays_o, const fl
   char* wsb = (char*)ws;
   const bool full = ws_bytes >= w.total;  // else: hashed slices for every level, float-atomic flush
   const uint32_t stripes = (N + 1023u) / 1024u;
-  hipLaunchKernelGGL(normalise_kernel, dim3(stripes), dim3(1024), 0, st, ps, N, g, (float*)(wsb + w.xnorm));
+  if (!reuse_coords) hipLaunchKernelGGL(normalise_kernel, dim3(stripes), dim3(1024), 0, st, ps, N, g, (float*)(wsb + w.xnorm));
   const uint32_t items = ps.x ? N : (uint32_t)R;            // boxes: per point, or per ray (two end points each)
   const uint32_t nboxes = (items + 1023u) / 1024u;          // <= stripes
   const uint32_t direct_rays = (!ps.x && R <= 4096) ? (uint32_t)R : 0u;  // few rays: meta_reduce_kernel takes their boxes itself
-  if (!direct_rays) hipLaunchKernelGGL(bounds_kernel, dim3(nboxes), dim3(1024), 0, st, ps, items, g, (float*)(wsb + w.bounds_part));
+  if (!direct_rays && !reuse_coords) hipLaunchKernelGGL(bounds_kernel, dim3(nboxes), dim3(1024), 0, st, ps, items, g, (float*)(wsb + w.bounds_part));
   uint32_t* abs_part = (uint32_t*)(wsb + w.abs_part);
   int abs_blocks = 0;
   if (!dy_absmax) {

@@ -15,6 +15,7 @@ from . import _lib
 from ._lib import BF16, F32, PLANAR, ROWS, HbrError, check, lib, require_gpu
 
 _ws_cache = {}
+_MAX_SCATTER_WS = 8 << 30  # largest K2 workspace allocated for the reproducible (slab) flush
 
 
 def _stream() -> int:
@@ -117,8 +118,9 @@ def hash_encode_fwd(geom: HashGeom, tables: torch.Tensor, x: Optional[torch.Tens
 
 def hash_encode_bwd(geom: HashGeom, dy: torch.Tensor, dtables: torch.Tensor, x: Optional[torch.Tensor] = None, rays=None,
                     layout: int = ROWS, algo: int = 0, dy_absmax: Optional[torch.Tensor] = None, deterministic: bool = True):
-    """Accumulates into dtables [L,T,F] fp32.  algo 0 = auto (LDS-slice fixed-point kernel from 65536 points), 1 = global
-    float atomics, 2 = LDS-slice kernel.  `deterministic` (algo 2): reduce the chunk partials in a fixed order (full
+    """Accumulates into dtables [L,T,F] fp32.  algo 0 = auto (LDS fixed-point kernels from 65536 points), 1 = global
+    float atomics, 2 = LDS kernels, 3 = LDS kernels re-using the coordinates the previous call (same points, same
+    stream) left in the workspace.  `deterministic` (algo 2): reduce the chunk partials in a fixed order (full
     workspace) instead of with float atomics.  `dy_absmax` [L] fp32 on the device: per-level max |dy| if the caller
     already has it."""
     require_gpu(dy)
@@ -138,9 +140,16 @@ def hash_encode_bwd(geom: HashGeom, dy: torch.Tensor, dtables: torch.Tensor, x: 
     if R * S == 0:
         return dtables
     sc, mu = geom.c_args()
-    size_fn = lib().hbr_hash_bwd_workspace_bytes if deterministic else lib().hbr_hash_bwd_workspace_bytes_min
-    nws = size_fn(R * S, geom.L, geom.T, geom.F, algo)
-    ws = _workspace("hash_bwd", nws, dy.device) if nws else None
+    nws = lib().hbr_hash_bwd_workspace_bytes(R * S, geom.L, geom.T, geom.F, algo) if deterministic else 0
+    if not deterministic or nws > _MAX_SCATTER_WS:
+        # the chunk slabs grow with T (8 x L x 2 x T floats): beyond a few GiB fall back to the float-atomic flush
+        nws = lib().hbr_hash_bwd_workspace_bytes_min(R * S, geom.L, geom.T, geom.F, algo)
+    if algo == 3:  # coordinates of the previous call must still be there: never (re)allocate for this call
+        ws = _ws_cache.get(("hash_bwd", dy.device, _stream()))
+        if ws is None or ws.numel() < nws:
+            raise HbrError("algo 3 re-uses the previous hash_encode_bwd call's workspace on this stream: none (large enough) exists")
+    else:
+        ws = _workspace("hash_bwd", nws, dy.device) if nws else None
     if dy_absmax is not None:
         dy_absmax = _f32c(dy_absmax)
     check(lib().hbr_hash_encode_bwd(_ptr(x), _ptr(o), _ptr(d), _ptr(t), R, S, dy.data_ptr(), layout, stride, dtype, _ptr(dy_absmax),

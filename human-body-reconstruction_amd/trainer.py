@@ -139,9 +139,11 @@ class HashNeRFTrainer:
             red.launch(self.grad[nt:])
 
             def scatter_halves():  # timed as ONE hash_bwd span (both launches), like the single-launch path
-                for lo, hi, piece in ((half, g.L, self.grad[cut:nt]), (0, half, self.grad[:cut])):
+                lds = self.scatter_algo in (0, 2) and R * S >= 65536  # the second half re-uses the first half's coordinates
+                for k, (lo, hi, piece) in enumerate(((half, g.L, self.grad[cut:nt]), (0, half, self.grad[:cut]))):
                     sub = ops.HashGeom(g.scales[lo:hi], g.mu, g.sigma, g.T, g.F)
-                    ops.hash_encode_bwd(sub, dfeat[lo:hi], self.g_tab[lo:hi], rays=rays, layout=PLANAR, algo=self.scatter_algo,
+                    ops.hash_encode_bwd(sub, dfeat[lo:hi], self.g_tab[lo:hi], rays=rays, layout=PLANAR,
+                                        algo=(2 if k == 0 else 3) if lds else self.scatter_algo,
                                         dy_absmax=None if amax is None else amax[lo:hi])
                     red.launch(piece)
 

@@ -96,6 +96,9 @@ int hbr_hash_encode_fwd(const float* x, const float* rays_o, const float* rays_d
  *                With the full workspace the chunk partials are reduced in a fixed order and the result of a launch
  *                is bitwise reproducible; with only the first hbr_hash_bwd_workspace_bytes_min() bytes they are
  *                added with float atomics (same values up to the order of <= chunks fp32 additions per entry).
+ *            3 = 2, re-using the normalised coordinates the PREVIOUS algo-2/3 call left in `ws`: same points, same
+ *                mu/sigma, same `ws` (a launch over another range of levels - the multi-GPU trainer scatters the levels
+ *                in two calls so that each half's all-reduce overlaps the other half's kernel)
  *            0 = auto: 2 when N >= 65536, T <= 2^28 and the workspace suffices, else 1
  *   ws       16-byte-aligned scratch of hbr_hash_bwd_workspace_bytes() bytes (normalised coordinates, per-level
  *            maxima, per-chunk partial tables); contents are dead after the call

@@ -109,11 +109,17 @@ def test_k2_level_halves_equal_single_launch(ops, algo, dt):
     ops.hash_encode_bwd(geom, dy, one, rays=rays, layout=PLANAR, algo=algo)
     two = torch.zeros((L, T, 2), device=DEV)
     half = L // 2
-    for lo, hi in ((half, L), (0, half)):
+    for k, (lo, hi) in enumerate(((half, L), (0, half))):
         sub = ops.HashGeom(geom.scales[lo:hi], geom.mu, geom.sigma, geom.T, geom.F)
-        ops.hash_encode_bwd(sub, dy[lo:hi], two[lo:hi], rays=rays, layout=PLANAR, algo=algo)
+        # the second LDS launch re-uses the first one's normalised coordinates (algo 3), as the trainer does
+        ops.hash_encode_bwd(sub, dy[lo:hi], two[lo:hi], rays=rays, layout=PLANAR, algo=3 if (algo == 2 and k == 1) else algo)
     if algo == 2:
         assert torch.equal(one, two)
+        three = torch.zeros((L, T, 2), device=DEV)
+        for lo, hi in ((half, L), (0, half)):  # ... and two independent algo-2 launches give the same bits
+            sub = ops.HashGeom(geom.scales[lo:hi], geom.mu, geom.sigma, geom.T, geom.F)
+            ops.hash_encode_bwd(sub, dy[lo:hi], three[lo:hi], rays=rays, layout=PLANAR, algo=2)
+        assert torch.equal(one, three)
     else:
         assert torch.allclose(one, two, rtol=1e-4, atol=1e-5 * float(one.abs().max()))
 
