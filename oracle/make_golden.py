@@ -359,6 +359,25 @@ def main():
         g13["g." + name] = p.grad.numpy()
     np.savez_compressed(os.path.join(OUT, "g13_masked_render.npz"), **g13)
 
+    # ---------------- G14: BASELINE config 1 - vanilla positional-encoding NeRF through vol_render ---------
+    # (train.py:16-19's objects with a narrow trunk so that the weights fit a fixture: d_filter 32 instead of 256)
+    p14 = ref_cpu.vanilla_nerf_init(1414, d_filter=32)
+    net = ref.vol_renderer.NeRF(d_input=60, n_layers=8, d_filter=32, skip=(4,), d_viewdirs=60)
+    net.load_state_dict(p14)
+    pe10 = quiet(ref.encoder.PositionalEncoder, 3, 10)
+    vr14 = ref.vol_renderer.Volume_Renderer(H=8, W=8, K=Kd, near=2.0, far=6.0, device="cpu", Pos_encode=pe10, Dir_encode=pe10,
+                                            max_dim=2 ** 10, sigma_val=torch.tensor(float(sigma)), mu=torch.from_numpy(mu))
+    cap = {}
+    ref.vol_renderer.calc_color = spy
+    with torch.no_grad():
+        Cr14, _, _ = quiet(vr14.vol_render, net, dvec, o, num_samples=S, t=torch.from_numpy(t), update_mask=False, dir_norm=dn,
+                           hierarchical=False)
+    ref.vol_renderer.calc_color = orig_cc
+    g14 = dict(Cr=Cr14.numpy(), sig_out=cap["sigma"], rgb_out=cap["rgb"], state_keys=np.array(list(net.state_dict().keys())))
+    for k, v in p14.items():
+        g14["p." + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "g14_vanilla_nerf.npz"), **g14)
+
     # ---------------- G10: PSNR + bounding box -----------------------------------------
     a = torch.from_numpy(f32(rng.uniform(0, 1, (50, 3))))
     b = torch.from_numpy(f32(rng.uniform(0, 1, (50, 3))))

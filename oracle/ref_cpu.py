@@ -442,3 +442,55 @@ def synthetic_scene_rays(R: int, seed: int = 0, radius: float = 4.03, near: floa
         sg, rgb = analytic_field(pts)
         gts.append(composite(t, rgb, sg, 1)[0])
     return o, d, torch.ones((R, 1), device=device), torch.cat(gts).clamp(0, 1)
+
+
+# --------------------------------------------------------------------------------------
+# BASELINE config 1 (CPU plumbing): the vanilla positional-encoding NeRF     vol_renderer.py:12-86, train.py:16-19
+# --------------------------------------------------------------------------------------
+# Outside the accelerated path ("OUT OF SCOPE for kernels") - restated here only so that the reference's own
+# CPU-runnable configuration has a pinned check: PositionalEncoder(3, 10) on points and directions, the 8-layer MLP
+# with a skip connection, then the same masked assign + compositing as the hash path.
+def vanilla_nerf_init(seed: int, d_input: int = 60, d_viewdirs: int = 60, n_layers: int = 8, d_filter: int = 256, skip=(4,)) -> dict:
+    """nn.Linear default init from a numpy stream; keys follow the reference's state dict (`layers.i`, `alpha_out`,
+    `rgb_filters`, `branch`, `output`)."""
+    rng = np.random.default_rng(seed)
+    shapes = {"layers.0": (d_filter, d_input)}
+    for i in range(n_layers - 1):  # layer i+1 follows the concat when i is a skip index (vol_renderer.py:33-35)
+        shapes[f"layers.{i + 1}"] = (d_filter, d_filter + d_input if i in skip else d_filter)
+    shapes.update({"alpha_out": (1, d_filter), "rgb_filters": (d_filter, d_filter), "branch": (d_filter // 2, d_filter + d_viewdirs),
+                   "output": (3, d_filter // 2)})
+    p = {}
+    for k, (o, i) in shapes.items():
+        b = 1.0 / math.sqrt(i)
+        p[k + ".weight"] = torch.from_numpy(rng.uniform(-b, b, (o, i)).astype(np.float32))
+        p[k + ".bias"] = torch.from_numpy(rng.uniform(-b, b, (o,)).astype(np.float32))
+    return p
+
+
+def vanilla_nerf_forward(x: torch.Tensor, viewdirs: torch.Tensor, p: dict, n_layers: int = 8, skip=(4,)) -> torch.Tensor:
+    """NeRF.forward with view directions (vol_renderer.py:50-86): ReLU after every trunk layer, the input re-attached
+    after layer `skip`; alpha = sigmoid(alpha_out(h)); rgb = relu(output(relu(branch(cat(rgb_filters(h), dirs)))));
+    returns [N,4] = (rgb, alpha)."""
+    lin = torch.nn.functional.linear
+    h = x
+    for i in range(n_layers):
+        h = torch.relu(lin(h, p[f"layers.{i}.weight"], p[f"layers.{i}.bias"]))
+        if i in skip:
+            h = torch.cat([h, x], dim=-1)
+    alpha = torch.sigmoid(lin(h, p["alpha_out.weight"], p["alpha_out.bias"]))
+    c = lin(h, p["rgb_filters.weight"], p["rgb_filters.bias"])
+    c = torch.relu(lin(torch.cat([c, viewdirs], dim=-1), p["branch.weight"], p["branch.bias"]))
+    c = torch.relu(lin(c, p["output.weight"], p["output.bias"]))
+    return torch.cat([c, alpha], dim=-1)
+
+
+def render_vanilla(o, d, t, dir_norm, p, num_freq: int = 10, n_layers: int = 8, skip=(4,)):
+    """vol_render with Pos_encode = Dir_encode = PositionalEncoder(3, num_freq), all-true occupancy grid:
+    returns (Cr [R,3], sigma [R,S], rgb [R,S,3])."""
+    R, S = o.shape[0], t.shape[0]
+    pts = sample_points(o, d, t).reshape(-1, 3)
+    dirs = d[:, None, :].expand(R, S, 3).reshape(-1, 3)
+    out = vanilla_nerf_forward(dir_encode(pts, num_freq), dir_encode(dirs, num_freq), p, n_layers, skip)
+    sig, rgb = out[:, 3].reshape(R, S), out[:, 0:3].reshape(R, S, 3)
+    Cr, _ = composite(t, rgb, sig, dir_norm)
+    return Cr, sig, rgb

@@ -234,3 +234,30 @@ def test_g13_masked_render_with_mixed_occupancy_grid():
     assert np.allclose(got, g["dtables"], rtol=1e-3, atol=1e-5 * np.abs(g["dtables"]).max())
     for k, p in params.items():
         assert np.allclose(p.grad.numpy(), g["g." + k], rtol=1e-3, atol=1e-5 * np.abs(g["g." + k]).max()), k
+
+
+def test_g14_config1_vanilla_positional_encoding_nerf():
+    """BASELINE config 1 (train.py's positional-encoding NeRF; CPU plumbing, outside the accelerated path): the oracle's
+    restatement of NeRF.forward + vol_render against the reference's own modules (vol_renderer.py:12-86,141-223)."""
+    g = load_golden("g14_vanilla_nerf.npz")
+    g8 = load_golden("g8_render_step.npz")
+    p = {k[2:]: T_(v) for k, v in g.items() if k.startswith("p.")}
+    assert [k for k in g["state_keys"]] == list(p.keys())  # same names and order as the reference's state dict
+    o, d, dn, t = (T_(g8[k]) for k in ("o", "d", "dir_norm", "t"))
+    Cr, sig, rgb = ref_cpu.render_vanilla(o, d, t, dn, p)
+    assert np.allclose(sig.numpy(), g["sig_out"], rtol=1e-4, atol=1e-5)
+    assert np.allclose(rgb.numpy(), g["rgb_out"], rtol=1e-4, atol=1e-5)
+    assert np.allclose(Cr.numpy(), g["Cr"], rtol=1e-4, atol=1e-5)
+
+
+def test_config1_plumbing_at_baseline_size():
+    """4096 rays x 64 samples through PositionalEncoder(3,10) x 2 + NeRF(d_input=60, d_viewdirs=60),
+    near 2 / far 6, seed 0 - shapes and finite values (this configuration is plumbing on the CPU; no kernel serves it)."""
+    torch.manual_seed(0)
+    R, S = 4096, 64
+    o, d, dn, _ = ref_cpu.synthetic_rays(R, seed=0)
+    t = ref_cpu.strat_jitter_to_t(2.0, 6.0, S, torch.rand(S))
+    with torch.no_grad():
+        Cr, sig, rgb = ref_cpu.render_vanilla(o, d, t, dn, ref_cpu.vanilla_nerf_init(0))
+    assert Cr.shape == (R, 3) and sig.shape == (R, S) and rgb.shape == (R, S, 3)
+    assert bool(torch.isfinite(Cr).all()) and float(sig.min()) >= 0.0 and float(sig.max()) <= 1.0 and float(rgb.min()) >= 0.0
