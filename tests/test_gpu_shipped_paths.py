@@ -357,3 +357,32 @@ def test_shipped_path_training_vs_cpu_oracle_psnr():
     assert np.allclose(l1[:10], ref_losses[:10], rtol=2e-2), (l1[:10], ref_losses[:10])
     assert p_ref > p_init + 10 and p1 > p_init + 10, (p_init, p_ref, p1)
     assert abs(p1 - p_ref) < 0.5, (p1, p_ref)
+
+
+@pytest.mark.parametrize("T,layout,dt,outside", [(2 ** 16, "rows", torch.float32, True), (1000, "planar", torch.bfloat16, False),
+                                                   (2 ** 12, "rows", torch.bfloat16, True), (2 ** 14 + 77, "planar", torch.float32, True)])
+def test_k2_lds_kernels_edge_shapes_vs_oracle(ops, T, layout, dt, outside):
+    """The LDS scatter kernels away from the benchmark's shape, against the oracle: EXPLICIT points (no ray structure:
+    the boxes come from the points themselves), N = 70 001 (a partial last stripe, an odd level stride for the
+    vector loads), rows and planar dy in fp32 and bf16, tables smaller than a slice / not a power of two (int64
+    modulo path, also for the dense levels' vertex hashing), and points outside the box (negative cells: torch's
+    `.long()` truncates toward zero, the per-corner path of the hashed kernel)."""
+    from hbr_amd._lib import PLANAR, ROWS
+    N, L = 70001, 16
+    rng = np.random.default_rng(int(T) % 977)
+    lo, hi = (-0.08, 0.5) if outside else (0.0, 0.55)
+    mu, sigma = torch.tensor([-1.0, 0.5, 2.0]), torch.tensor(3.0)
+    x = torch.from_numpy(rng.uniform(lo, hi, (N, 3)).astype(np.float32)) * sigma + mu
+    sc = ref_cpu.level_scales(16, 2048.0, L)
+    geom = ops.HashGeom(tuple(float(v) for v in sc), tuple(float(v) for v in mu), float(sigma), int(T), 2)
+    dy = torch.from_numpy((rng.standard_normal((N, L * 2)) * 10.0 ** rng.uniform(-3, 0, (N, 1))).astype(np.float32)).to(dt)
+    ref = ref_cpu.hash_encode_backward(x, dy.float(), sc, mu, sigma, int(T)).numpy()
+    dyd = dy.to(DEV) if layout == "rows" else dy.reshape(N, L, 2).permute(1, 0, 2).contiguous().to(DEV)
+    got = torch.zeros((L, int(T), 2), device=DEV)
+    ops.hash_encode_bwd(geom, dyd, got, x=x.to(DEV), layout=ROWS if layout == "rows" else PLANAR, algo=2)
+    g = got.cpu().numpy()
+    assert np.allclose(g, ref, rtol=1e-4, atol=1e-6 * np.abs(ref).max())
+    assert not np.any((g != 0) & (ref == 0))
+    again = torch.zeros_like(got)
+    ops.hash_encode_bwd(geom, dyd, again, x=x.to(DEV), layout=ROWS if layout == "rows" else PLANAR, algo=2)
+    assert torch.equal(again, got)
