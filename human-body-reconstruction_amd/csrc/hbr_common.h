@@ -123,10 +123,12 @@ __device__ __forceinline__ void corner_weights(const Cell& c, float w[8]) {
   w[4] = __fmul_rn(xy00, c.fz); w[5] = __fmul_rn(xy10, c.fz); w[6] = __fmul_rn(xy01, c.fz); w[7] = __fmul_rn(xy11, c.fz);
 }
 
-__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
-  __bf16 ha = (__bf16)a, hb = (__bf16)b;
-  uint16_t ua = __builtin_bit_cast(uint16_t, ha), ub = __builtin_bit_cast(uint16_t, hb);
-  return (uint32_t)ua | ((uint32_t)ub << 16);
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {  // one v_cvt_pk_bf16_f32 (round to nearest even)
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  f32x2_t v;
+  v[0] = a; v[1] = b;
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ float bf16_lo(uint32_t v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t v) { return __uint_as_float(v & 0xffff0000u); }

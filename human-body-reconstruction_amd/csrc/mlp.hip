@@ -87,6 +87,10 @@ struct PBf16 {
   __device__ static __forceinline__ void mfma_acc(frag a, frag b, f32x16& c) {
     asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
   }
+  // same, pinned in program order relative to the other volatile statements (xch_take slots VALU work behind each one)
+  __device__ static __forceinline__ void mfma_acc_ordered(frag a, frag b, f32x16& c) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  }
   __device__ static __forceinline__ frag from_acc(const f32x16& acc, int s) {
     frag f;
 #pragma unroll
@@ -268,6 +272,37 @@ __device__ __forceinline__ void dense(const char* img, int fbase, const float* b
   }
 }
 
+// The backward chain requests the first group of a dense's weight fragments BEFORE it parks the previous layer's
+// fragments in the exchange (xch_put): LDS operations complete in order, so reads issued after the 16 exchange writes
+// would wait for all of them in front of the first MFMA.
+constexpr int kPreFrags = 4;
+template <class P, int NK>
+__device__ __forceinline__ void dense_request(const char* img, int fbase, int lofs, typename P::frag (&pre)[kPreFrags]) {
+#pragma unroll
+  for (int g = 0; g < kPreFrags; ++g)
+    if (g < NK) pre[g] = ldw<P>(img, fbase + g, lofs);
+}
+template <class P, int NOUT, int NK>
+__device__ __forceinline__ void dense_requested(const char* img, int fbase, int lofs, const typename P::frag (&pre)[kPreFrags],
+                                                const typename P::frag (&x)[NK], f32x16 (&acc)[NOUT]) {
+  static_assert(P::ELEMS == 8 && NK <= kPreFrags, "bf16 groups of four k-steps");
+#pragma unroll
+  for (int m = 0; m < NOUT; ++m)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[m][q] = 0.f;
+  typename P::frag nxt[kPreFrags];
+  if constexpr (NOUT == 2) {  // the second output tile's fragments, in flight under the first tile's MFMAs
+#pragma unroll
+    for (int g = 0; g < NK; ++g) nxt[g] = ldw<P>(img, fbase + NK + g, lofs);
+  }
+#pragma unroll
+  for (int g = 0; g < NK; ++g) acc[0] = P::mfma(pre[g], x[g], acc[0]);
+  if constexpr (NOUT == 2) {
+#pragma unroll
+    for (int g = 0; g < NK; ++g) acc[1] = P::mfma(nxt[g], x[g], acc[1]);
+  }
+}
+
 // Packed 16-bit helpers on bf16 pairs (one VGPR = two activations).  Inline asm: hipcc 7.2 scalarises 8-wide `short`
 // vectors and miscompiled the element-wise update of a bit-cast vector in a loop (round 1), and for `fmaxf(x, 0)` it
 // emits a canonicalising `v_max_f32 x, x, x` in front of the max - 2 instructions per activation, 256 per tile.
@@ -283,6 +318,13 @@ __device__ __forceinline__ uint32_t pk_keep_where_nonzero(uint32_t grad, uint32_
   uint32_t m, r;
   asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(act), "v"(ones));
   asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(grad), "v"(m));
+  return r;
+}
+
+__device__ __forceinline__ uint32_t pk_keep_where_nonzero_ordered(uint32_t grad, uint32_t act, uint32_t ones) {
+  uint32_t m, r;
+  asm volatile("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(act), "v"(ones));
+  asm volatile("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(grad), "v"(m));
   return r;
 }
 
@@ -655,6 +697,15 @@ __global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(const float* __res
 // layers with two give each tile to a pair of waves that split the four sources.  The exchange buffer is double-buffered, so one
 // barrier per layer suffices: a wave can only overwrite buffer b two layers later, after the next barrier, which
 // every wave reaches only after finishing its reads of b.  No LDS atomics, no second recompute of the forward.
+#ifndef HBR_K4_WPRE
+#define HBR_K4_WPRE 0  // bf16: request a dense's first weight fragments before the exchange writes (dense_request)
+#endif
+#ifndef HBR_K4_TAKE_HALVES
+#define HBR_K4_TAKE_HALVES 0  // bf16: the owner reads two source waves at a time (32 instead of 64 fragment registers)
+#endif
+#ifndef HBR_K4_INTERLEAVE
+#define HBR_K4_INTERLEAVE 1  // bf16: ReLU-mask epilogue word by word behind the owner MFMAs (mask_take)
+#endif
 #ifndef HBR_XCH_TR
 #define HBR_XCH_TR 1  // bf16: exchange through a [point][feature] image + ds_read_b64_tr_b16 (0: identity-MFMA transposes)
 #endif
@@ -752,11 +803,22 @@ __device__ __forceinline__ void xch_put(char* xch, int buf, int lane, int wv, co
 }
 
 // ---- second half: meet the workgroup, then accumulate MY dW^T tile of the layer over the source waves' fragments
-template <class P, int NIN, int NOUT>
-__device__ __forceinline__ void xch_take(char* xch, int& buf, int lane, int wv, f32x16& acc, float* colsum) {
+// `epi(k)`, k = 0..WORDS-1: the caller's VALU epilogue of the dense it has just issued (re-pack + ReLU mask of one
+// output word), cut into words.  The bf16 path slots WORDS / (number of owner MFMAs) of them behind each owner MFMA:
+// the two are independent, so the epilogue runs in the shadow of the 32-cycle MFMAs instead of in front of them (one
+// wave per SIMD: nothing else would overlap them).  The statements involved are volatile asm, which pins the order.
+struct NoEpi {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+template <class P, int NIN, int NOUT, int WORDS = 0, class Epi = NoEpi>
+__device__ __forceinline__ void xch_take(char* xch, int& buf, int lane, int wv, f32x16& acc, float* colsum, Epi epi = Epi()) {
   using X = Xch<P>;
   using O = Own<NIN, NOUT>;
   constexpr int NSRC = O::NSRC;
+  if constexpr (!(P::ELEMS == 8 && HBR_XCH_TR)) {
+#pragma unroll
+    for (int k = 0; k < WORDS; ++k) epi(k);
+  }
   __syncthreads();
   const O own(wv);
   if constexpr (P::ELEMS == 8 && HBR_XCH_TR) {
@@ -768,39 +830,47 @@ __device__ __forceinline__ void xch_take(char* xch, int& buf, int lane, int wv, 
     const char* b0 = src + xch_off(8 * h + q, 8 + 4 * own.m + 2 * g + (p >> 1));
     const char* b1 = src + xch_off(8 * h + 4 + q, 8 + 4 * own.m + 2 * g + (p >> 1));
     bf16x8 fa[NSRC][2], fb[NSRC][2];
-#pragma unroll
-    for (int w = 0; w < NSRC; ++w)
+    auto request = [&](int w) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {  // points 16s + 8h + j of source wave src0 + w
         const int o = w * X::SLOT_B + s * 16 * 256;
         fa[w][s] = lds_tr_frag(a0 + o, a1 + o);
         fb[w][s] = lds_tr_frag(b0 + o, b1 + o);
       }
-    // all reads are issued before the first MFMA; each source's fragments are then claimed in turn, so the waits are
-    // lgkmcnt(remaining) rather than eight full drains (hipcc otherwise sinks every read next to its MFMA)
+    };
+    // which sources' dZ this wave sums into the bias gradient: every (out tile, source) pair is summed by exactly one
+    // of the waves that read it - the owners of (n, m) for n = 0, 1 split the source list by n
+    auto sums_bias = [&](int w) {
+      if constexpr (O::tiles == 4) return (w < 2) == (own.n == 0);
+      else if constexpr (NIN == 2) return w == own.n;  // NOUT == 1: the n = 0 and n = 1 owners read the same two sources
+      else return true;                                // NIN == 1: one owner per (m, source pair)
+    };
+    constexpr bool kHalves = HBR_K4_TAKE_HALVES && NSRC == 4;
+    // the reads are issued ahead of the MFMAs (all of them, or two sources ahead); each source's fragments are then
+    // claimed in turn, so the waits are lgkmcnt(remaining) rather than full drains (hipcc otherwise sinks every read
+    // next to its MFMA)
+#pragma unroll
+    for (int w = 0; w < (kHalves ? 2 : NSRC); ++w) request(w);
+    float bs = 0.f;
 #pragma unroll
     for (int w = 0; w < NSRC; ++w) {
       asm volatile("" : "+v"(fa[w][0]), "+v"(fa[w][1]), "+v"(fb[w][0]), "+v"(fb[w][1]));
 #pragma unroll
-      for (int s = 0; s < 2; ++s) PBf16::mfma_acc(fa[w][s], fb[w][s], acc);
-    }
-    // bias gradient of out tile m = sum over points of dZ.  Every (out tile, source) pair is summed by exactly one of
-    // the waves that read it: the owners of (n, m) for n = 0, 1 split a four-source list by n.
-    float bs = 0.f;
-    if constexpr (O::tiles == 4) {
-      if (own.n == 0) {
-        bs = frag_sum(fb[0][0], bs); bs = frag_sum(fb[0][1], bs); bs = frag_sum(fb[1][0], bs); bs = frag_sum(fb[1][1], bs);
-      } else {
-        bs = frag_sum(fb[2][0], bs); bs = frag_sum(fb[2][1], bs); bs = frag_sum(fb[3][0], bs); bs = frag_sum(fb[3][1], bs);
+      for (int s = 0; s < 2; ++s) {
+        if constexpr (WORDS > 0) PBf16::mfma_acc_ordered(fa[w][s], fb[w][s], acc);
+        else PBf16::mfma_acc(fa[w][s], fb[w][s], acc);
+        constexpr int NM = 2 * NSRC;
+        const int i = 2 * w + s;
+#pragma unroll
+        for (int k = (i * WORDS) / NM; k < ((i + 1) * WORDS) / NM; ++k) epi(k);
       }
-    } else if constexpr (NIN == 2) {  // NOUT == 1: the n = 0 and n = 1 owners read the same two sources
-      if (own.n == 0) {
-        bs = frag_sum(fb[0][0], bs); bs = frag_sum(fb[0][1], bs);
-      } else {
-        bs = frag_sum(fb[1][0], bs); bs = frag_sum(fb[1][1], bs);
+      if (sums_bias(w)) {
+        bs = frag_sum(fb[w][0], bs);
+        bs = frag_sum(fb[w][1], bs);
       }
-    } else {  // NIN == 1: one owner per (m, source pair)
-      bs = frag_sum(fb[0][0], bs); bs = frag_sum(fb[0][1], bs); bs = frag_sum(fb[1][0], bs); bs = frag_sum(fb[1][1], bs);
+      if constexpr (kHalves) {
+        if (w + 2 < NSRC) request(w + 2);
+      }
     }
     colsum[0] += (own.m == 0) ? bs : 0.f;
     if constexpr (NOUT == 2) colsum[1] += (own.m == 1) ? bs : 0.f;
@@ -845,6 +915,34 @@ __device__ __forceinline__ void xch_take(char* xch, int& buf, int lane, int wv, 
     }
   }
   buf ^= 1;
+}
+
+// dZ = mask(dX) of the dense just issued (mask_frags), and the owner half of the PREVIOUS layer's exchange (xch_take).
+// bf16: word by word behind the owner MFMAs; f32: one after the other.
+template <class P, int NT, int NIN, int NOUT>
+__device__ __forceinline__ void mask_take(f32x16 (&a)[NT], const typename P::frag (&h)[NT * P::S32],
+                                          typename P::frag (&out)[NT * P::S32], char* xch, int& buf, int lane, int wv,
+                                          f32x16& acc, float* colsum) {
+  if constexpr (P::ELEMS == 8 && HBR_XCH_TR && HBR_K4_INTERLEAVE) {
+    constexpr int WORDS = NT * P::S32 * 4;
+    uint32_t ow[WORDS];
+    uint32_t ones = 0x00010001u;
+    asm volatile("" : "+v"(ones));
+    xch_take<P, NIN, NOUT, WORDS>(xch, buf, lane, wv, acc, colsum, [&](int k) {
+      const int f = k >> 2, t = f / P::S32, s = f % P::S32, j = k & 3;
+      const uint32_t g = pack_bf16x2(a[t][8 * s + 2 * j], a[t][8 * s + 2 * j + 1]);
+      ow[k] = pk_keep_where_nonzero_ordered(g, __builtin_bit_cast(u32x4, h[f])[j], ones);
+    });
+#pragma unroll
+    for (int f = 0; f < NT * P::S32; ++f) {
+      u32x4 w;
+      w[0] = ow[4 * f]; w[1] = ow[4 * f + 1]; w[2] = ow[4 * f + 2]; w[3] = ow[4 * f + 3];
+      out[f] = __builtin_bit_cast(bf16x8, w);
+    }
+  } else {
+    mask_frags<P, NT>(a, h, out);
+    xch_take<P, NIN, NOUT>(xch, buf, lane, wv, acc, colsum);
+  }
 }
 
 template <class P, int LAYOUT, int DT, bool WLDS>
@@ -915,58 +1013,68 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
 #pragma unroll
       for (int s = 0; s < P::S8; ++s) dz3[s] = P::from_acc(a, s);
     }
+    constexpr bool kWPre = (P::ELEMS == 8) && HBR_K4_WPRE;
+    typename P::frag wpre[kPreFrags];
+    if constexpr (kWPre) dense_request<P, P::S8>(img, T::b_base(C3), lofs, wpre);
     xch_put<P, 2, 1, 2 * P::S32, P::S8>(xch, buf, lane, wv, sv.c2, dz3, bsum + db_base(C3));  // take: after the next layer's dense
     // ---- C2
     typename P::frag dzc2[2 * P::S32];
     {
       f32x16 a[2];
-      dense<P, 2, P::S8, false>(img, T::b_base(C3), nullptr, lane, lofs, dz3, a);
-      mask_frags<P, 2>(a, sv.c2, dzc2);
+      if constexpr (kWPre) dense_requested<P, 2, P::S8>(img, T::b_base(C3), lofs, wpre, dz3, a);
+      else dense<P, 2, P::S8, false>(img, T::b_base(C3), nullptr, lane, lofs, dz3, a);
+      mask_take<P, 2, 2, 1>(a, sv.c2, dzc2, xch, buf, lane, wv, acc[C3], bsum + db_base(C3));
     }
-    xch_take<P, 2, 1>(xch, buf, lane, wv, acc[C3], bsum + db_base(C3));
+    if constexpr (kWPre) dense_request<P, 2 * P::S32>(img, T::b_base(C2), lofs, wpre);
     xch_put<P, 2, 2, 2 * P::S32, 2 * P::S32>(xch, buf, lane, wv, sv.c1, dzc2, bsum + db_base(C2));  // take: after the next layer's dense
     // ---- C1
     typename P::frag dzc1[2 * P::S32];
     {
       f32x16 a[2];
-      dense<P, 2, 2 * P::S32, false>(img, T::b_base(C2), nullptr, lane, lofs, dzc2, a);
-      mask_frags<P, 2>(a, sv.c1, dzc1);
+      if constexpr (kWPre) dense_requested<P, 2, 2 * P::S32>(img, T::b_base(C2), lofs, wpre, dzc2, a);
+      else dense<P, 2, 2 * P::S32, false>(img, T::b_base(C2), nullptr, lane, lofs, dzc2, a);
+      mask_take<P, 2, 2, 2>(a, sv.c1, dzc1, xch, buf, lane, wv, acc[C2], bsum + db_base(C2));
     }
-    xch_take<P, 2, 2>(xch, buf, lane, wv, acc[C2], bsum + db_base(C2));
+    if constexpr (kWPre) dense_request<P, 2 * P::S32>(img, T::b_base(C1), lofs, wpre);
     xch_put<P, 2, 2, P::S32 + P::S8, 2 * P::S32>(xch, buf, lane, wv, sv.cin, dzc1, bsum + db_base(C1));  // take: after the next layer's dense
     // ---- L3: ds rows 1..15 = d cin slots 1..15 ; row 0 = d sigma * lrelu'(s0)
     typename P::frag dz_s[P::S16];
     {
       f32x16 a[1];
-      dense<P, 1, 2 * P::S32, false>(img, T::b_base(C1), nullptr, lane, lofs, dzc1, a);
+      if constexpr (kWPre) dense_requested<P, 1, 2 * P::S32>(img, T::b_base(C1), lofs, wpre, dzc1, a);
+      else dense<P, 1, 2 * P::S32, false>(img, T::b_base(C1), nullptr, lane, lofs, dzc1, a);
       if (h == 0) a[0][0] = dO.w * (sv.s0 > 0.f ? 1.f : 0.01f);
 #pragma unroll
       for (int s = 0; s < P::S16; ++s) dz_s[s] = P::from_acc(a[0], s);
     }
     xch_take<P, 2, 2>(xch, buf, lane, wv, acc[C1], bsum + db_base(C1));
+    if constexpr (kWPre) dense_request<P, P::S16>(img, T::b_base(L3), lofs, wpre);
     xch_put<P, 2, 1, 2 * P::S32, P::S16>(xch, buf, lane, wv, sv.h2, dz_s, bsum + db_base(L3));  // take: after the next layer's dense
     // ---- L2
     typename P::frag dz2[2 * P::S32];
     {
       f32x16 a[2];
-      dense<P, 2, P::S16, false>(img, T::b_base(L3), nullptr, lane, lofs, dz_s, a);
-      mask_frags<P, 2>(a, sv.h2, dz2);
+      if constexpr (kWPre) dense_requested<P, 2, P::S16>(img, T::b_base(L3), lofs, wpre, dz_s, a);
+      else dense<P, 2, P::S16, false>(img, T::b_base(L3), nullptr, lane, lofs, dz_s, a);
+      mask_take<P, 2, 2, 1>(a, sv.h2, dz2, xch, buf, lane, wv, acc[L3], bsum + db_base(L3));
     }
-    xch_take<P, 2, 1>(xch, buf, lane, wv, acc[L3], bsum + db_base(L3));
+    if constexpr (kWPre) dense_request<P, 2 * P::S32>(img, T::b_base(L2), lofs, wpre);
     xch_put<P, 2, 2, 2 * P::S32, 2 * P::S32>(xch, buf, lane, wv, sv.h1, dz2, bsum + db_base(L2));  // take: after the next layer's dense
     // ---- L1
     typename P::frag dz1[2 * P::S32];
     {
       f32x16 a[2];
-      dense<P, 2, 2 * P::S32, false>(img, T::b_base(L2), nullptr, lane, lofs, dz2, a);
-      mask_frags<P, 2>(a, sv.h1, dz1);
+      if constexpr (kWPre) dense_requested<P, 2, 2 * P::S32>(img, T::b_base(L2), lofs, wpre, dz2, a);
+      else dense<P, 2, 2 * P::S32, false>(img, T::b_base(L2), nullptr, lane, lofs, dz2, a);
+      mask_take<P, 2, 2, 2>(a, sv.h1, dz1, xch, buf, lane, wv, acc[L2], bsum + db_base(L2));
     }
-    xch_take<P, 2, 2>(xch, buf, lane, wv, acc[L2], bsum + db_base(L2));
+    if constexpr (kWPre) dense_request<P, 2 * P::S32>(img, T::b_base(L1), lofs, wpre);
     xch_put<P, 1, 2, P::S32, 2 * P::S32>(xch, buf, lane, wv, sv.x0, dz1, bsum + db_base(L1));  // take: after the next layer's dense
     // ---- d feat
     if (dfd.p) {
       f32x16 a[1];
-      dense<P, 1, 2 * P::S32, false>(img, T::b_base(L1), nullptr, lane, lofs, dz1, a);
+      if constexpr (kWPre) dense_requested<P, 1, 2 * P::S32>(img, T::b_base(L1), lofs, wpre, dz1, a);
+      else dense<P, 1, 2 * P::S32, false>(img, T::b_base(L1), nullptr, lane, lofs, dz1, a);
       if (valid) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {

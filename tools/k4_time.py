@@ -9,16 +9,17 @@ R, S = 16000, 128
 N = R * S
 o, d, dn, gt = ref_cpu.synthetic_rays(R, seed=0)
 pe = ops.dir_encode(d.to(dev), 4)
-feat = torch.randn((16, N, 2), device=dev) * 0.3
+feat = (torch.randn((16, N, 2), device=dev) * 0.3).to(torch.bfloat16 if os.environ.get("FEAT", "bf16") == "bf16" else torch.float32)
+amax = torch.zeros(16, device=dev)
 P = torch.cat([v.reshape(-1) for v in ref_cpu.mlp_init(0).values()]).to(dev)
 dout = torch.randn((N, 4), device=dev)
 dP = torch.zeros_like(P)
 for _ in range(3):
-    ops.mlp_bwd(feat, PLANAR, pe, S, P, BF16, dout, dP)
+    ops.mlp_bwd(feat, PLANAR, pe, S, P, BF16, dout, dP, absmax_out=amax)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(20):
-    ops.mlp_bwd(feat, PLANAR, pe, S, P, BF16, dout, dP)
+    ops.mlp_bwd(feat, PLANAR, pe, S, P, BF16, dout, dP, absmax_out=amax)
 e1.record(); torch.cuda.synchronize()
 print(os.environ.get("HBR_LIB", "default"), f"mlp_bwd bf16 {e0.elapsed_time(e1) / 20:.4f} ms", flush=True)
