@@ -20,6 +20,8 @@
 // Weights are re-packed into MFMA-fragment order by a tiny kernel on every call (parameters are updated in
 // place by the optimiser between calls; nothing is cached across calls), then held in LDS.
 #include "hbr_common.h"
+#include <cstdlib>
+#include <type_traits>
 
 namespace hbr {
 namespace mlp {
@@ -91,40 +93,46 @@ struct PBf16 {
   __device__ static __forceinline__ void mfma_acc_ordered(frag a, frag b, f32x16& c) {
     asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
   }
+  // operands that came straight from LDS reads (no VALU write in front of the MFMA): no wait states needed, and an
+  // s_nop costs a 4-cycle issue slot at one wave per SIMD
+  template <bool ORDERED, bool PAD>
+  __device__ static __forceinline__ void mfma_acc_lds(frag a, frag b, f32x16& c) {
+    if constexpr (PAD) {
+      if constexpr (ORDERED) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+      else asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    } else {
+      if constexpr (ORDERED) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+      else asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    }
+  }
+  // Vectors are always BUILT WHOLE from scalar words (initializer lists), never updated element by element: hipcc 7.2
+  // miscompiles element-wise writes into (bit-cast) vectors depending on the surrounding code - seen in round 1 as
+  // "all four words took the first word's value" and in round 2 as one instantiation (rows layout, fp32 features) of
+  // the forward kernel returning 15 % wrong outputs after an unrelated change elsewhere in the file.
+  __device__ static __forceinline__ frag from_words(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+    const u32x4 w = {w0, w1, w2, w3};
+    return __builtin_bit_cast(frag, w);
+  }
   __device__ static __forceinline__ frag from_acc(const f32x16& acc, int s) {
-    frag f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = (__bf16)acc[8 * s + j];
-    return f;
+    return from_words(pack_bf16x2(acc[8 * s], acc[8 * s + 1]), pack_bf16x2(acc[8 * s + 2], acc[8 * s + 3]),
+                      pack_bf16x2(acc[8 * s + 4], acc[8 * s + 5]), pack_bf16x2(acc[8 * s + 6], acc[8 * s + 7]));
   }
-  __device__ static __forceinline__ frag zero() {
-    frag f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = (__bf16)0.f;
-    return f;
-  }
+  __device__ static __forceinline__ frag zero() { return from_words(0u, 0u, 0u, 0u); }
   __device__ static __forceinline__ frag ident(int s, int lane) {
     const int r = lane & 31, h = lane >> 5;
-    frag f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = (__bf16)((r == rho(s, h, j)) ? 1.f : 0.f);
-    return f;
+    auto pair = [&](int j) { return (r == rho(s, h, j) ? 0x3f80u : 0u) | (r == rho(s, h, j + 1) ? 0x3f800000u : 0u); };
+    return from_words(pair(0), pair(2), pair(4), pair(6));
   }
   // the three k-steps of the colour net's first layer: L3 tile rows 0..15, PE 0..15, PE 16..23
   __device__ static __forceinline__ void cin(const f32x16& acc3, float4 peA, float4 peB, float4 peC, frag (&out)[3]) {
     out[0] = from_acc(acc3, 0);
-    out[1][0] = (__bf16)peA.x; out[1][1] = (__bf16)peA.y; out[1][2] = (__bf16)peA.z; out[1][3] = (__bf16)peA.w;
-    out[1][4] = (__bf16)peB.x; out[1][5] = (__bf16)peB.y; out[1][6] = (__bf16)peB.z; out[1][7] = (__bf16)peB.w;
-    out[2] = zero();
-    out[2][0] = (__bf16)peC.x; out[2][1] = (__bf16)peC.y; out[2][2] = (__bf16)peC.z; out[2][3] = (__bf16)peC.w;
+    out[1] = from_words(pack_bf16x2(peA.x, peA.y), pack_bf16x2(peA.z, peA.w), pack_bf16x2(peB.x, peB.y), pack_bf16x2(peB.z, peB.w));
+    out[2] = from_words(pack_bf16x2(peC.x, peC.y), pack_bf16x2(peC.z, peC.w), 0u, 0u);
   }
   // features of one point for step s: element j <- feature rho(s,h,j); v[4] are the (f0,f1) pairs of levels
   // 8s+2h, 8s+2h+1, 8s+4+2h, 8s+4+2h+1
   __device__ static __forceinline__ frag feat_frag(const float2 (&v)[4]) {
-    frag f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { f[2 * k] = (__bf16)v[k].x; f[2 * k + 1] = (__bf16)v[k].y; }
-    return f;
+    return from_words(pack_bf16x2(v[0].x, v[0].y), pack_bf16x2(v[1].x, v[1].y), pack_bf16x2(v[2].x, v[2].y), pack_bf16x2(v[3].x, v[3].y));
   }
 };
 
@@ -154,11 +162,23 @@ struct PF32 {
 // ------------------------------------------------------------------------------------------------
 // fragment-image tables (shared by the pack kernel and the compute kernels)
 // ------------------------------------------------------------------------------------------------
+// Reading a layer's bias into the accumulators costs 4 KiB of LDS traffic per 32x32 output tile (16 floats per lane) -
+// more than the tile's weight fragments in the narrow layers, 40 of the forward's 74 KiB per point tile, and the LDS
+// pipe (shared by the CU's four waves) is what bounds these kernels.  In bf16 mode the bias is instead one more
+// k-step: a weight fragment whose k = 0, 1, 2 columns hold the bias split into three bf16 parts (hi + mid + lo
+// reproduces the fp32 value to 2^-24 relative), multiplied by an activation fragment that is 1 on those k and 0
+// elsewhere: 1 KiB and one MFMA per tile, accumulators start from the inline constant 0.
+#ifndef HBR_BIAS_STEP
+#define HBR_BIAS_STEP 1
+#endif
 template <class P>
 struct Tab {
   // forward: output-feature tiles and k-steps (input slots) per layer
   __device__ __host__ static constexpr int f_out_tiles(int l) { return (l == L3 || l == C3) ? 1 : 2; }
-  __device__ __host__ static constexpr int f_ksteps(int l) { return l == L1 ? P::S32 : (l == C1 ? P::S32 + P::S8 : 2 * P::S32); }
+  // bf16: the bias rides on one more k-step per output tile (BIAS_STEP) instead of being read into the accumulators
+  static constexpr bool BIAS_STEP = (P::ELEMS == 8) && HBR_BIAS_STEP;
+  __device__ __host__ static constexpr int f_wsteps(int l) { return l == L1 ? P::S32 : (l == C1 ? P::S32 + P::S8 : 2 * P::S32); }
+  __device__ __host__ static constexpr int f_ksteps(int l) { return f_wsteps(l) + (BIAS_STEP ? 1 : 0); }
   __device__ __host__ static constexpr int f_base(int l) {
     int b = 0;
     for (int i = 0; i < l; ++i) b += f_out_tiles(i) * f_ksteps(i);
@@ -206,15 +226,28 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ par
     const int n = ks / P::S32, s = ks % P::S32;
     typename P::frag f;
     float vals[8];
+    if (fwd && T::BIAS_STEP && ks == nk - 1) {  // the bias step: k = 0, 1, 2 <- the three bf16 parts of bias[32m + r]
+      const int off = blog_offset(l, 32 * m + r);
+      float part[3] = {0.f, 0.f, 0.f}, rest = off >= 0 ? params[off] : 0.f;
+      for (int i = 0; i < 3; ++i) {
+        part[i] = (float)(__bf16)rest;
+        rest -= part[i];  // exact: rest and part[i] share their leading bits
+      }
 #pragma unroll
-    for (int j = 0; j < P::ELEMS; ++j) {
-      const int kk = 32 * n + P::rho(s, h, j);
-      const int off = fwd ? wlog_offset(l, 32 * m + r, kk) : wlog_offset(l, kk, 32 * m + r);
-      vals[j] = off >= 0 ? params[off] : 0.f;
+      for (int j = 0; j < P::ELEMS; ++j) {
+        const int kk = P::rho(0, h, j);
+        vals[j] = kk < 3 ? part[kk] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < P::ELEMS; ++j) {
+        const int kk = 32 * n + P::rho(s, h, j);
+        const int off = fwd ? wlog_offset(l, 32 * m + r, kk) : wlog_offset(l, kk, 32 * m + r);
+        vals[j] = off >= 0 ? params[off] : 0.f;
+      }
     }
     if constexpr (P::ELEMS == 8) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) f[j] = (__bf16)vals[j];
+      f = P::from_words(pack_bf16x2(vals[0], vals[1]), pack_bf16x2(vals[2], vals[3]), pack_bf16x2(vals[4], vals[5]), pack_bf16x2(vals[6], vals[7]));
     } else {
       f = vals[0];
     }
@@ -240,19 +273,37 @@ __device__ __forceinline__ int opaque_lane_offset(int lane) {
 }
 
 // acc[m] = bias ; acc[m] += sum_ks W_frag(m,ks) * x[ks]      (orientation 1)
-template <class P, int NOUT, int NK, bool BIAS>
+// BIAS: 0 none (backward), 1 read into the accumulators, 2 the extra k-step of the bf16 image (a bf16 image always
+// holds that fragment behind each output tile's weight fragments, whichever way the bias is applied)
+template <class P, int NOUT, int NK, int BIAS>
 __device__ __forceinline__ void dense(const char* img, int fbase, const float* bias, int lane, int lofs,
                                       const typename P::frag (&x)[NK], f32x16 (&acc)[NOUT]) {
   const int h = lane >> 5;
   const int bofs = lofs - lane * (int)sizeof(typename P::frag);  // opaque zero: keeps the bias loads inside the loop too
+  constexpr bool BSTEP = BIAS == 2 && Tab<P>::BIAS_STEP;
+  constexpr int MSTRIDE = NK + ((BIAS && Tab<P>::BIAS_STEP) ? 1 : 0);  // fragments per output tile in the image
 #pragma unroll
   for (int m = 0; m < NOUT; ++m) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (BIAS) b = *(const float4*)((const char*)bias + bofs + 4 * (32 * m + 8 * g + 4 * h));
+      if (BIAS && !BSTEP) b = *(const float4*)((const char*)bias + bofs + 4 * (32 * m + 8 * g + 4 * h));
       acc[m][4 * g + 0] = b.x; acc[m][4 * g + 1] = b.y; acc[m][4 * g + 2] = b.z; acc[m][4 * g + 3] = b.w;
     }
+  }
+  if constexpr (BSTEP) {
+    // activation fragment of the bias step: k = rho(0, h, j) in {0, 1, 2} <-> elements 0..2 of the h = 0 lanes
+    const typename P::frag ones = P::from_words(h ? 0u : 0x3f803f80u, h ? 0u : 0x00003f80u, 0u, 0u);
+#pragma unroll
+    for (int m = 0; m < NOUT; ++m) {  // all of a tile's fragments are requested before its first MFMA
+      typename P::frag wf[NK + 1];
+#pragma unroll
+      for (int g = 0; g <= NK; ++g) wf[g] = ldw<P>(img, fbase + m * (NK + 1) + g, lofs);
+#pragma unroll
+      for (int g = 0; g < NK; ++g) acc[m] = P::mfma(wf[g], x[g], acc[m]);
+      acc[m] = P::mfma(wf[NK], ones, acc[m]);
+    }
+    return;
   }
   // The weight fragments of a group of k-steps are all requested before the first MFMA of the group: left to itself
   // hipcc emits ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma per k-step, exposing the full LDS latency ~100 times per tile.
@@ -264,42 +315,11 @@ __device__ __forceinline__ void dense(const char* img, int fbase, const float* b
       typename P::frag wf[G];
 #pragma unroll
       for (int g = 0; g < G; ++g)
-        if (k0 + g < NK) wf[g] = ldw<P>(img, fbase + m * NK + k0 + g, lofs);
+        if (k0 + g < NK) wf[g] = ldw<P>(img, fbase + m * MSTRIDE + k0 + g, lofs);
 #pragma unroll
       for (int g = 0; g < G; ++g)
         if (k0 + g < NK) acc[m] = P::mfma(wf[g], x[k0 + g], acc[m]);
     }
-  }
-}
-
-// The backward chain requests the first group of a dense's weight fragments BEFORE it parks the previous layer's
-// fragments in the exchange (xch_put): LDS operations complete in order, so reads issued after the 16 exchange writes
-// would wait for all of them in front of the first MFMA.
-constexpr int kPreFrags = 4;
-template <class P, int NK>
-__device__ __forceinline__ void dense_request(const char* img, int fbase, int lofs, typename P::frag (&pre)[kPreFrags]) {
-#pragma unroll
-  for (int g = 0; g < kPreFrags; ++g)
-    if (g < NK) pre[g] = ldw<P>(img, fbase + g, lofs);
-}
-template <class P, int NOUT, int NK>
-__device__ __forceinline__ void dense_requested(const char* img, int fbase, int lofs, const typename P::frag (&pre)[kPreFrags],
-                                                const typename P::frag (&x)[NK], f32x16 (&acc)[NOUT]) {
-  static_assert(P::ELEMS == 8 && NK <= kPreFrags, "bf16 groups of four k-steps");
-#pragma unroll
-  for (int m = 0; m < NOUT; ++m)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[m][q] = 0.f;
-  typename P::frag nxt[kPreFrags];
-  if constexpr (NOUT == 2) {  // the second output tile's fragments, in flight under the first tile's MFMAs
-#pragma unroll
-    for (int g = 0; g < NK; ++g) nxt[g] = ldw<P>(img, fbase + NK + g, lofs);
-  }
-#pragma unroll
-  for (int g = 0; g < NK; ++g) acc[0] = P::mfma(pre[g], x[g], acc[0]);
-  if constexpr (NOUT == 2) {
-#pragma unroll
-    for (int g = 0; g < NK; ++g) acc[1] = P::mfma(nxt[g], x[g], acc[1]);
   }
 }
 
@@ -314,17 +334,22 @@ __device__ __forceinline__ uint32_t pk_relu_bf16(uint32_t w) {
   asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(w));
   return r;
 }
+// (one asm statement for the pair: between two dependent statements hipcc pads an `s_nop 0` - 4 issue cycles at one
+// wave per SIMD - because it cannot see what the second one reads)
 __device__ __forceinline__ uint32_t pk_keep_where_nonzero(uint32_t grad, uint32_t act, uint32_t ones /* 0x00010001 */) {
-  uint32_t m, r;
-  asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(act), "v"(ones));
-  asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(grad), "v"(m));
+  uint32_t r;
+  asm("v_pk_min_u16 %0, %2, %3\n\tv_pk_mul_lo_u16 %0, %1, %0" : "=&v"(r) : "v"(grad), "v"(act), "v"(ones));
   return r;
 }
 
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ uint32_t pk_keep_where_nonzero_ordered(uint32_t grad, uint32_t act, uint32_t ones) {
-  uint32_t m, r;
-  asm volatile("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(act), "v"(ones));
-  asm volatile("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(grad), "v"(m));
+  uint32_t r;
+  asm volatile("v_pk_min_u16 %0, %2, %3\n\tv_pk_mul_lo_u16 %0, %1, %0" : "=&v"(r) : "v"(grad), "v"(act), "v"(ones));
   return r;
 }
 
@@ -338,10 +363,9 @@ __device__ __forceinline__ void relu_frags(f32x16 (&acc)[NT], typename P::frag (
     if constexpr (P::ELEMS == 8) {
 #pragma unroll
       for (int s = 0; s < P::S32; ++s) {
-        u32x4 w = __builtin_bit_cast(u32x4, P::from_acc(acc[t], s));
-#pragma unroll
-        for (int k = 0; k < 4; ++k) w[k] = pk_relu_bf16(w[k]);
-        out[t * P::S32 + s] = __builtin_bit_cast(bf16x8, w);
+        const f32x16& a = acc[t];
+        out[t * P::S32 + s] = PBf16::from_words(pk_relu_bf16(pack_bf16x2(a[8 * s], a[8 * s + 1])), pk_relu_bf16(pack_bf16x2(a[8 * s + 2], a[8 * s + 3])),
+                                                pk_relu_bf16(pack_bf16x2(a[8 * s + 4], a[8 * s + 5])), pk_relu_bf16(pack_bf16x2(a[8 * s + 6], a[8 * s + 7])));
       }
     } else {
 #pragma unroll
@@ -363,11 +387,12 @@ __device__ __forceinline__ void mask_frags(f32x16 (&acc)[NT], const typename P::
       asm volatile("" : "+v"(ones));  // keep it in one VGPR (the asm operands below are VGPR-only)
 #pragma unroll
       for (int s = 0; s < P::S32; ++s) {
-        u32x4 w = __builtin_bit_cast(u32x4, P::from_acc(acc[t], s));
+        const f32x16& a = acc[t];
         const u32x4 hw = __builtin_bit_cast(u32x4, h[t * P::S32 + s]);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) w[k] = pk_keep_where_nonzero(w[k], hw[k], ones);
-        out[t * P::S32 + s] = __builtin_bit_cast(bf16x8, w);
+        out[t * P::S32 + s] = PBf16::from_words(pk_keep_where_nonzero(pack_bf16x2(a[8 * s], a[8 * s + 1]), hw[0], ones),
+                                                pk_keep_where_nonzero(pack_bf16x2(a[8 * s + 2], a[8 * s + 3]), hw[1], ones),
+                                                pk_keep_where_nonzero(pack_bf16x2(a[8 * s + 4], a[8 * s + 5]), hw[2], ones),
+                                                pk_keep_where_nonzero(pack_bf16x2(a[8 * s + 6], a[8 * s + 7]), hw[3], ones));
       }
     } else {
 #pragma unroll
@@ -378,11 +403,59 @@ __device__ __forceinline__ void mask_frags(f32x16 (&acc)[NT], const typename P::
   }
 }
 
+// Development-only phase timer (tools/k4_phases.py builds a variant with -DHBR_K4_PROF=1; never in the shipped
+// library): wave 0 of workgroup 0 adds the shader-clock cycles between successive marks to k4_prof[phase].
+#ifndef HBR_K4_PROF
+#define HBR_K4_PROF 0
+#endif
+#if HBR_K4_PROF
+__device__ unsigned long long k4_prof[64];
+struct PhaseClock {
+  long long t0 = 0;
+  bool on = false;
+  long long c0 = 0, r0 = 0;
+  __device__ __forceinline__ void start() {
+    on = blockIdx.x == 0 && threadIdx.x == 0;
+    c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime();
+    t0 = clock64();
+  }
+  // shader-clock and 100 MHz reference ticks of the whole sweep -> the clock the chip held (k4_prof[62] / [63] x 100 MHz)
+  __device__ __forceinline__ void finish() {
+    const long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (on) { k4_prof[62] += (unsigned long long)(c1 - c0); k4_prof[63] += (unsigned long long)(r1 - r0); }
+  }
+  __device__ __forceinline__ void mark(int i) {
+    if (HBR_K4_PROF == 2) return;  // whole-sweep stamps only: the unperturbed cycle count and clock
+    const long long t1 = clock64();
+    if (on) k4_prof[i] += (unsigned long long)(t1 - t0);
+    t0 = clock64();
+  }
+  // the same after the values in `v` exist (an MFMA result, a re-packed fragment): pins the producers before the stamp
+  template <class V>
+  __device__ __forceinline__ void mark_after(int i, V& v) {
+    if (HBR_K4_PROF == 2) return;
+    asm volatile("" : "+v"(v));
+    mark(i);
+  }
+};
+#else
+struct PhaseClock {
+  __device__ __forceinline__ void start() {}
+  __device__ __forceinline__ void finish() {}
+  __device__ __forceinline__ void mark(int) {}
+  template <class V>
+  __device__ __forceinline__ void mark_after(int, V&) {}
+};
+#endif
 struct FeatSrc {
   const void* p;
   int64_t stride;  // rows layout
   uint32_t N;
+  uint32_t addr32;  // every byte offset the tile loads / stores form (features, d out, directions) fits 32 bits
 };
+// N and N / group up to which FeatSrc::addr32 holds: 3 N x 8 B (planar fp32: lane half h reads level 2h + k), 16 B x N
+// (d out), 96 B x rays
+constexpr int64_t kAddr32MaxN = 1LL << 27, kAddr32MaxRays = 1LL << 25;
 
 struct PeSrc {
   const float* pe;  // [G,24] encoded view directions
@@ -398,9 +471,57 @@ struct TileIn {
   float4 dO;                // d out (backward only)
 };
 
+// Where a lane's next tile is: its point n = ray * group + rem.  A sweep advances every lane by the same number of
+// points per round, so the ray index is carried along with two adds and a compare instead of a 32-bit division per
+// tile (~35 VALU), and in the planar layout the loads take a 32-bit offset from a wave-uniform (SGPR) level base
+// instead of 64-bit per-lane address arithmetic.
+struct TileCursor {
+  uint32_t n, ray, rem;
+  uint32_t dn, dray, drem, group;
+  __device__ __forceinline__ void start(uint32_t n0, uint32_t points_per_round, uint32_t g) {
+    group = g; n = n0; ray = n0 / g; rem = n0 - ray * g;
+    dn = points_per_round; dray = points_per_round / g; drem = points_per_round - dray * g;
+  }
+  __device__ __forceinline__ void advance() {
+    n += dn; ray += dray; rem += drem;
+    const bool carry = rem >= group;
+    rem -= carry ? group : 0u;
+    ray += carry ? 1u : 0u;
+  }
+};
+
+// byte offset of (level 2h, point n) from the start of a planar buffer with ES-byte (f0,f1) pairs; the lane's level
+// 4(k>>1) + 2h + (k&1) is (4(k>>1) + (k&1)) * N * ES further - a wave-uniform amount
+template <int ES>
+__device__ __forceinline__ uint32_t planar_off(uint32_t N, uint32_t n, int h) { return (2u * (uint32_t)h * N + n) * ES; }
+template <int ES>
+__device__ __forceinline__ size_t planar_level_base(uint32_t N, int k) { return (size_t)(4 * (k >> 1) + (k & 1)) * N * ES; }
+
 template <int LAYOUT, int DT, bool WITH_DOUT>
-__device__ __forceinline__ void load_tile_in(const FeatSrc& fs, const PeSrc& ps, const float* dout, uint32_t n, bool valid, int h,
-                                             TileIn& ti) {
+__device__ __forceinline__ void load_tile_in(const FeatSrc& fs, const PeSrc& ps, const float* dout, const TileCursor& c, bool valid,
+                                             int h, TileIn& ti) {
+  const uint32_t n = c.n;
+  if (LAYOUT == HBR_LAYOUT_PLANAR && fs.addr32) {
+    constexpr int ES = DT == HBR_F32 ? 8 : 4;
+    const uint32_t off = planar_off<ES>(fs.N, n, h);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ti.v[k] = make_float2(0.f, 0.f);
+    ti.peA = make_float4(0, 0, 0, 0); ti.peB = ti.peA; ti.peC = ti.peA; ti.dO = ti.peA;
+    if (valid) {  // one branch around all of the tile's loads
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const char* lb = (const char*)fs.p + planar_level_base<ES>(fs.N, k);
+        if (DT == HBR_F32) ti.v[k] = *(const float2*)(lb + off);
+        else ti.v[k].x = __uint_as_float(*(const uint32_t*)(lb + off));
+      }
+      const char* pr = (const char*)ps.pe + (c.ray * 96u + 16u * (uint32_t)h);
+      ti.peA = *(const float4*)pr;
+      ti.peB = *(const float4*)(pr + 32);
+      ti.peC = *(const float4*)(pr + 64);
+      if (WITH_DOUT && h == 0) ti.dO = *(const float4*)((const char*)dout + n * 16u);
+    }
+    return;
+  }
   // feature pair (2l, 2l+1) of level l; a lane in half h owns levels {2h,2h+1, 4+2h,4+2h+1, 8+.., 12+..}
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -418,7 +539,7 @@ __device__ __forceinline__ void load_tile_in(const FeatSrc& fs, const PeSrc& ps,
   }
   ti.peA = make_float4(0, 0, 0, 0); ti.peB = ti.peA; ti.peC = ti.peA; ti.dO = ti.peA;
   if (valid) {
-    const float* pr = ps.pe + (size_t)(n / ps.group) * 24;
+    const float* pr = ps.pe + (size_t)c.ray * 24;
     ti.peA = *(const float4*)(pr + 4 * h);
     ti.peB = *(const float4*)(pr + 8 + 4 * h);
     ti.peC = *(const float4*)(pr + 16 + 4 * h);
@@ -468,42 +589,58 @@ struct Saved {
 };
 
 
-template <class P, int DT>  // DT: storage type of the feature buffer the tile was loaded from
-__device__ __forceinline__ void forward_tile(const char* img, const float* bias, const TileIn& ti, int lane, Saved<P>& sv) {
+// DT: storage type of the feature buffer the tile was loaded from.  BSTEP: bf16 bias by the extra k-step (the backward
+// kernel: 40 fewer LDS reads and 32 fewer live registers per tile) or read into the accumulators (the forward kernel,
+// which has the occupancy to hide those reads and is 10 % faster without the ten extra MFMAs)
+template <class P, int DT, bool BSTEP>
+__device__ __forceinline__ void forward_tile(const char* img, const float* bias, const TileIn& ti, int lane, Saved<P>& sv,
+                                             PhaseClock& pc) {
   using T = Tab<P>;
   const int h = lane >> 5;
   const int lofs = opaque_lane_offset<P>(lane);
   feat_frags<P, DT>(ti, sv.x0);
+  pc.mark_after(20, sv.x0[P::S32 - 1]);  // the tile's inputs have arrived
   const float4 peA = ti.peA, peB = ti.peB, peC = ti.peC;
   {
     f32x16 a[2];
-    dense<P, 2, P::S32, true>(img, T::f_base(L1), bias + 64 * L1, lane, lofs, sv.x0, a);
+    dense<P, 2, P::S32, (BSTEP ? 2 : 1)>(img, T::f_base(L1), bias + 64 * L1, lane, lofs, sv.x0, a);
+    pc.mark_after(21, a[1]);
     relu_frags<P, 2>(a, sv.h1);
+    pc.mark_after(22, sv.h1[2 * P::S32 - 1]);
   }
   {
     f32x16 a[2];
-    dense<P, 2, 2 * P::S32, true>(img, T::f_base(L2), bias + 64 * L2, lane, lofs, sv.h1, a);
+    dense<P, 2, 2 * P::S32, (BSTEP ? 2 : 1)>(img, T::f_base(L2), bias + 64 * L2, lane, lofs, sv.h1, a);
+    pc.mark_after(23, a[1]);
     relu_frags<P, 2>(a, sv.h2);
+    pc.mark_after(24, sv.h2[2 * P::S32 - 1]);
   }
   {
     f32x16 a[1];
-    dense<P, 1, 2 * P::S32, true>(img, T::f_base(L3), bias + 64 * L3, lane, lofs, sv.h2, a);
+    dense<P, 1, 2 * P::S32, (BSTEP ? 2 : 1)>(img, T::f_base(L3), bias + 64 * L3, lane, lofs, sv.h2, a);
+    pc.mark_after(25, a[0]);
     sv.s0 = a[0][0];
     P::cin(a[0], peA, peB, peC, sv.cin);
+    pc.mark_after(26, sv.cin[P::S32 + P::S8 - 1]);
   }
   {
     f32x16 a[2];
-    dense<P, 2, P::S32 + P::S8, true>(img, T::f_base(C1), bias + 64 * C1, lane, lofs, sv.cin, a);
+    dense<P, 2, P::S32 + P::S8, (BSTEP ? 2 : 1)>(img, T::f_base(C1), bias + 64 * C1, lane, lofs, sv.cin, a);
+    pc.mark_after(27, a[1]);
     relu_frags<P, 2>(a, sv.c1);
+    pc.mark_after(28, sv.c1[2 * P::S32 - 1]);
   }
   {
     f32x16 a[2];
-    dense<P, 2, 2 * P::S32, true>(img, T::f_base(C2), bias + 64 * C2, lane, lofs, sv.c1, a);
+    dense<P, 2, 2 * P::S32, (BSTEP ? 2 : 1)>(img, T::f_base(C2), bias + 64 * C2, lane, lofs, sv.c1, a);
+    pc.mark_after(29, a[1]);
     relu_frags<P, 2>(a, sv.c2);
+    pc.mark_after(30, sv.c2[2 * P::S32 - 1]);
   }
   {
     f32x16 a[1];
-    dense<P, 1, 2 * P::S32, true>(img, T::f_base(C3), bias + 64 * C3, lane, lofs, sv.c2, a);
+    dense<P, 1, 2 * P::S32, (BSTEP ? 2 : 1)>(img, T::f_base(C3), bias + 64 * C3, lane, lofs, sv.c2, a);
+    pc.mark_after(31, a[0]);
     sv.raw[0] = a[0][0]; sv.raw[1] = a[0][1]; sv.raw[2] = a[0][2];
   }
 }
@@ -533,13 +670,16 @@ __global__ __launch_bounds__(kFwdWaves * 64) void mlp_fwd_kernel(const char* __r
   const float* bias = (const float*)(smem + T::BIAS_OFF_F);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t ntiles = (fs.N + 31) / 32;
-  for (uint32_t tile = blockIdx.x * kFwdWaves + wv; tile < ntiles; tile += gridDim.x * kFwdWaves) {
-    const uint32_t n = tile * 32 + (lane & 31);
+  TileCursor cur;
+  cur.start((blockIdx.x * kFwdWaves + wv) * 32 + (lane & 31), gridDim.x * kFwdWaves * 32, ps.group);
+  for (uint32_t tile = blockIdx.x * kFwdWaves + wv; tile < ntiles; tile += gridDim.x * kFwdWaves, cur.advance()) {
+    const uint32_t n = cur.n;
     const bool valid = n < fs.N;
     Saved<P> sv;
     TileIn ti;
-    load_tile_in<LAYOUT, DT, false>(fs, ps, nullptr, n, valid, lane >> 5, ti);
-    forward_tile<P, DT>(smem, bias, ti, lane, sv);
+    load_tile_in<LAYOUT, DT, false>(fs, ps, nullptr, cur, valid, lane >> 5, ti);
+    PhaseClock pc;
+    forward_tile<P, DT, false>(smem, bias, ti, lane, sv, pc);
     if (valid && lane < 32) {
       // a sample whose occupancy cell is False keeps the zeros the reference initialises sigma/rgb with (vol_renderer.py:213-217)
       const bool kept = !keep || keep[n];
@@ -604,27 +744,36 @@ static_assert(kSlabWg % 32 == 0, "reduce kernel takes 32 entries per block");
 constexpr int kMaxBwdBlocks = 256;                 // one workgroup per CU
 __device__ __host__ constexpr int64_t slab_offset_bytes(int64_t img_bytes) { return (img_bytes + 255) / 256 * 256; }
 
+// Column order of the bf16 exchange image (xch_put): a lane parks its 8 fragment elements as ONE 16-byte chunk, so
+// position c = 8h + j of a 16-feature group holds feature 8(j>>2) + 4h + (j&3) - bits 2 and 3 of the index swapped.
+// The owners' tiles come out with rows and columns in image order; this (an involution) maps a tile index back.
+__device__ __host__ constexpr int xch_feature(int pos, bool swapped) {
+  return swapped ? ((pos & ~12) | ((pos & 4) << 1) | ((pos & 8) >> 1)) : pos;
+}
+
 // flat-parameter offset of slab entry e = (wave, register, lane), or -1 for a padding row/column of its tile
-__device__ __forceinline__ int slab_entry_offset(int e) {
+__device__ __forceinline__ int slab_entry_offset(int e, bool swapped) {
   const int lane = e & 63, r = (e >> 6) % kSlabRegs, wv = e / kSlabWave, h = lane >> 5;
+  const int out = xch_feature(lane & 31, swapped);
   if (r < NLAYER * 16) {
     const int l = r >> 4, q = r & 15;
     const int nout = (l == L3 || l == C3) ? 1 : 2;
     const int tiles = ((l == L1) ? 1 : 2) * nout;
     const int tau = (tiles == 4) ? wv : (wv >> 1);
-    return wlog_offset(l, 32 * (tau % nout) + (lane & 31), 32 * (tau / nout) + acc_row(q, h));
+    return wlog_offset(l, 32 * (tau % nout) + out, 32 * (tau / nout) + xch_feature(acc_row(q, h), swapped));
   }
   const int i = r - NLAYER * 16;  // bias partial i: layer l, out tile m (db_base)
   int l = NLAYER - 1;
   while (db_base(l) > i) --l;
-  return blog_offset(l, 32 * (i - db_base(l)) + (lane & 31));
+  return blog_offset(l, 32 * (i - db_base(l)) + out);
 }
 
 // Stage 1: 256 threads = 32 consecutive slab entries x 8 parts; part p sums slabs p, p+8, ... with four loads in
 // flight, the eight partials are combined through LDS in a fixed order (a single thread per entry walking all 256
 // slabs was latency-bound: 62 us) -> tot[entry].  Sixteen extra blocks reduce the per-wave feature-gradient maxima.
 __global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(const float* __restrict__ slabs, int nblocks, float* __restrict__ tot,
-                                                            const uint32_t* __restrict__ abs_part, float* __restrict__ absmax_out) {
+                                                            const uint32_t* __restrict__ abs_part, float* __restrict__ absmax_out,
+                                                            bool swapped) {
   __shared__ float part[8][32];
   if (blockIdx.x >= kSlabWg / 32) {  // 16 extra blocks, one per level: max |d feat| over the waves' partials -> absmax_out[level]
     __shared__ uint32_t wmax[4];
@@ -641,7 +790,7 @@ __global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(const float* __restr
   const int el = threadIdx.x & 31, p = threadIdx.x >> 5;
   const float* src = slabs + blockIdx.x * 32 + el;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  if (slab_entry_offset(blockIdx.x * 32 + el) >= 0) {  // padding entries (over half of the slab) are never read
+  if (slab_entry_offset(blockIdx.x * 32 + el, swapped) >= 0) {  // padding entries (over half of the slab) are never read
     int b = p;
     for (; b + 24 < nblocks; b += 32) {
       a0 += src[(size_t)b * kSlabWg];
@@ -661,11 +810,11 @@ __global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(const float* __restr
 // a tile of a two-tile layer, and the 4 waves x 2 lane halves that hold partial sums of one bias row - so ONE of them
 // (the "leader": the even wave / wave 0's lower half) adds up its siblings in a fixed order and the others return:
 // every parameter has exactly one writer and one summation order, i.e. the MLP gradient is bitwise reproducible.
-__global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(const float* __restrict__ tot, float* __restrict__ dparams) {
+__global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(const float* __restrict__ tot, float* __restrict__ dparams, bool swapped) {
   const int e = blockIdx.x * 256 + threadIdx.x;  // (wave, register, lane) of the slab layout
   if (e >= kSlabWg) return;
   const int lane = e & 63, r = (e >> 6) % kSlabRegs, wv = e / kSlabWave, h = lane >> 5;
-  const int off = slab_entry_offset(e);
+  const int off = slab_entry_offset(e, swapped);
   if (off < 0) return;
   float v = tot[e];
   if (r < NLAYER * 16) {
@@ -697,11 +846,11 @@ __global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(const float* __res
 // layers with two give each tile to a pair of waves that split the four sources.  The exchange buffer is double-buffered, so one
 // barrier per layer suffices: a wave can only overwrite buffer b two layers later, after the next barrier, which
 // every wave reaches only after finishing its reads of b.  No LDS atomics, no second recompute of the forward.
-#ifndef HBR_K4_WPRE
-#define HBR_K4_WPRE 0  // bf16: request a dense's first weight fragments before the exchange writes (dense_request)
-#endif
 #ifndef HBR_K4_TAKE_HALVES
-#define HBR_K4_TAKE_HALVES 0  // bf16: the owner reads two source waves at a time (32 instead of 64 fragment registers)
+#define HBR_K4_TAKE_HALVES 1  // bf16: the owner reads two source waves at a time (32 instead of 64 fragment registers)
+#endif
+#ifndef HBR_K4_NOP
+#define HBR_K4_NOP 1  // s_nop in front of the owner MFMAs: 2 = every one, 1 = the first after operands may have moved
 #endif
 #ifndef HBR_K4_INTERLEAVE
 #define HBR_K4_INTERLEAVE 1  // bf16: ReLU-mask epilogue word by word behind the owner MFMAs (mask_take)
@@ -709,6 +858,11 @@ __global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(const float* __res
 #ifndef HBR_XCH_TR
 #define HBR_XCH_TR 1  // bf16: exchange through a [point][feature] image + ds_read_b64_tr_b16 (0: identity-MFMA transposes)
 #endif
+#ifndef HBR_XCH_W16
+#define HBR_XCH_W16 1  // bf16 image: one 16-byte write per fragment (columns in xch_feature order) instead of two 8-byte ones
+#endif
+template <class P>
+constexpr bool kXchSwapped = (P::ELEMS == 8) && HBR_XCH_TR && HBR_XCH_W16;
 template <class P>
 struct Xch {
   static constexpr int FRAG_B = (int)sizeof(typename P::frag) * 64;
@@ -731,18 +885,6 @@ __device__ __forceinline__ bf16x8 lds_tr_frag(const char* lo, const char* hi) {
   const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)lo);
   const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)hi);
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-__device__ __forceinline__ float frag_sum(bf16x8 f, float acc) {
-  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-  bf16x2 one;
-  one[0] = (__bf16)1.f; one[1] = (__bf16)1.f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    bf16x2 p;
-    p[0] = f[2 * i]; p[1] = f[2 * i + 1];
-    acc = __builtin_amdgcn_fdot2_f32_bf16(p, one, acc, false);
-  }
-  return acc;
 }
 
 // Which dW^T tile [in tile n][out tile m] of a layer a wave owns, and over which source waves.  Four-tile layers:
@@ -770,21 +912,33 @@ __device__ __forceinline__ void xch_put(char* xch, int buf, int lane, int wv, co
   if constexpr (P::ELEMS == 8 && HBR_XCH_TR) {
     static_assert(X::SLOT_B == 32 * 256, "slot = 32 point rows of 256 B");
     const int pt = lane & 31, h = lane >> 5;
-    char* mine = xch + buf * X::BUF_B + wv * X::SLOT_B + 256 * pt + 8 * h;
     const int sw16 = 16 * (((pt & 3) << 2) | ((pt >> 2) & 3));
+    if constexpr (HBR_XCH_W16) {
+      // fragment (tile ks/2, step ks%2) = the 16 features 32n+16s..: this lane's 8 elements (features 4h.., 8+4h..)
+      // go to chunk h of the pair as one 16-byte write; the 8 lanes a write cycle serves hit 8 different chunks
+      char* mine = xch + buf * X::BUF_B + wv * X::SLOT_B + 256 * pt;
 #pragma unroll
-    for (int ks = 0; ks < NKX; ++ks) {  // fragment (tile ks/2, step ks%2): elements 0..3 -> features 32n+16s+4h.., 4..7 -> +8
-      const u32x4 w = __builtin_bit_cast(u32x4, x[ks]);
-      const int ch = 4 * (ks / 2) + 2 * (ks % 2);
-      *(uint2*)(mine + ((16 * ch) ^ sw16)) = make_uint2(w[0], w[1]);
-      *(uint2*)(mine + ((16 * (ch + 1)) ^ sw16)) = make_uint2(w[2], w[3]);
-    }
+      for (int ks = 0; ks < NKX; ++ks)
+        *(u32x4*)(mine + ((16 * (4 * (ks / 2) + 2 * (ks % 2) + h)) ^ sw16)) = __builtin_bit_cast(u32x4, x[ks]);
 #pragma unroll
-    for (int ks = 0; ks < NKZ; ++ks) {
-      const u32x4 w = __builtin_bit_cast(u32x4, dz[ks]);
-      const int ch = 8 + 4 * (ks / 2) + 2 * (ks % 2);
-      *(uint2*)(mine + ((16 * ch) ^ sw16)) = make_uint2(w[0], w[1]);
-      *(uint2*)(mine + ((16 * (ch + 1)) ^ sw16)) = make_uint2(w[2], w[3]);
+      for (int ks = 0; ks < NKZ; ++ks)
+        *(u32x4*)(mine + ((16 * (8 + 4 * (ks / 2) + 2 * (ks % 2) + h)) ^ sw16)) = __builtin_bit_cast(u32x4, dz[ks]);
+    } else {
+      char* mine = xch + buf * X::BUF_B + wv * X::SLOT_B + 256 * pt + 8 * h;
+#pragma unroll
+      for (int ks = 0; ks < NKX; ++ks) {  // elements 0..3 -> features 32n+16s+4h.., 4..7 -> +8: columns in feature order
+        const u32x4 w = __builtin_bit_cast(u32x4, x[ks]);
+        const int ch = 4 * (ks / 2) + 2 * (ks % 2);
+        *(uint2*)(mine + ((16 * ch) ^ sw16)) = make_uint2(w[0], w[1]);
+        *(uint2*)(mine + ((16 * (ch + 1)) ^ sw16)) = make_uint2(w[2], w[3]);
+      }
+#pragma unroll
+      for (int ks = 0; ks < NKZ; ++ks) {
+        const u32x4 w = __builtin_bit_cast(u32x4, dz[ks]);
+        const int ch = 8 + 4 * (ks / 2) + 2 * (ks % 2);
+        *(uint2*)(mine + ((16 * ch) ^ sw16)) = make_uint2(w[0], w[1]);
+        *(uint2*)(mine + ((16 * (ch + 1)) ^ sw16)) = make_uint2(w[2], w[3]);
+      }
     }
   } else {
     typename P::frag xt[NIN][P::S32], zt[NOUT][P::S32];
@@ -807,11 +961,28 @@ __device__ __forceinline__ void xch_put(char* xch, int buf, int lane, int wv, co
 // output word), cut into words.  The bf16 path slots WORDS / (number of owner MFMAs) of them behind each owner MFMA:
 // the two are independent, so the epilogue runs in the shadow of the 32-cycle MFMAs instead of in front of them (one
 // wave per SIMD: nothing else would overlap them).  The statements involved are volatile asm, which pins the order.
+// bf16 bias gradients: ONE accumulator tile for all six layers.  Layer l's sums (over the points, of the out tile this
+// wave owns) live in row acc_row(l, 0) of it, i.e. in register l of the lanes 0..31 (column = out feature).
+struct BiasAcc {
+  f32x16 tile;
+  uint32_t onehot[NLAYER];  // per layer: a bf16 pair of ones in the lanes whose MFMA row is that layer's, else 0
+  __device__ __forceinline__ void init(int lane) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tile[q] = 0.f;
+#pragma unroll
+    for (int l = 0; l < NLAYER; ++l) {
+      onehot[l] = ((lane & 31) == acc_row(l, 0)) ? 0x3f803f80u : 0u;
+      asm volatile("" : "+v"(onehot[l]));  // computed once, long before the asm MFMAs that read it
+    }
+  }
+};
+
 struct NoEpi {
   __device__ __forceinline__ void operator()(int) const {}
 };
 template <class P, int NIN, int NOUT, int WORDS = 0, class Epi = NoEpi>
-__device__ __forceinline__ void xch_take(char* xch, int& buf, int lane, int wv, f32x16& acc, float* colsum, Epi epi = Epi()) {
+__device__ __forceinline__ void xch_take(char* xch, int& buf, int lane, int wv, f32x16& acc, BiasAcc& ba, int layer, PhaseClock& pc,
+                                         int ph, Epi epi = Epi()) {
   using X = Xch<P>;
   using O = Own<NIN, NOUT>;
   constexpr int NSRC = O::NSRC;
@@ -819,7 +990,9 @@ __device__ __forceinline__ void xch_take(char* xch, int& buf, int lane, int wv, 
 #pragma unroll
     for (int k = 0; k < WORDS; ++k) epi(k);
   }
+  pc.mark(ph);      // put + dense (+ the f32 epilogue)
   __syncthreads();
+  pc.mark(ph + 1);  // waiting for the slowest wave
   const O own(wv);
   if constexpr (P::ELEMS == 8 && HBR_XCH_TR) {
     // lane (group g of its half, q, p) supplies row q, columns 4p..4p+3 of its group's 4-point x 16-feature block
@@ -851,31 +1024,34 @@ __device__ __forceinline__ void xch_take(char* xch, int& buf, int lane, int wv, 
     // next to its MFMA)
 #pragma unroll
     for (int w = 0; w < (kHalves ? 2 : NSRC); ++w) request(w);
-    float bs = 0.f;
+    const u32x4 ohw = {ba.onehot[layer], ba.onehot[layer], ba.onehot[layer], ba.onehot[layer]};
+    const bf16x8 onehot = __builtin_bit_cast(bf16x8, ohw);
 #pragma unroll
     for (int w = 0; w < NSRC; ++w) {
       asm volatile("" : "+v"(fa[w][0]), "+v"(fa[w][1]), "+v"(fb[w][0]), "+v"(fb[w][1]));
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        if constexpr (WORDS > 0) PBf16::mfma_acc_ordered(fa[w][s], fb[w][s], acc);
-        else PBf16::mfma_acc(fa[w][s], fb[w][s], acc);
+        // the claim above may have moved fragments with v_mov: pad the first MFMA behind it (VALU write -> MFMA read)
+        if (s == 0) PBf16::mfma_acc_lds<(WORDS > 0), (HBR_K4_NOP >= 1)>(fa[w][s], fb[w][s], acc);
+        else PBf16::mfma_acc_lds<(WORDS > 0), (HBR_K4_NOP == 2)>(fa[w][s], fb[w][s], acc);
         constexpr int NM = 2 * NSRC;
         const int i = 2 * w + s;
 #pragma unroll
         for (int k = (i * WORDS) / NM; k < ((i + 1) * WORDS) / NM; ++k) epi(k);
       }
+      // bias gradient of out tile m = sum over points of dZ: one more MFMA per fragment, against an operand that is 1 in
+      // row `layer`'s slot of the shared bias tile and 0 elsewhere (8 issue cycles; four v_dot2c per fragment cost ~40)
       if (sums_bias(w)) {
-        bs = frag_sum(fb[w][0], bs);
-        bs = frag_sum(fb[w][1], bs);
+        PBf16::mfma_acc_lds<(WORDS > 0), (HBR_K4_NOP >= 1)>(onehot, fb[w][0], ba.tile);  // `onehot` is assembled by v_mov
+        PBf16::mfma_acc_lds<(WORDS > 0), (HBR_K4_NOP == 2)>(onehot, fb[w][1], ba.tile);
       }
       if constexpr (kHalves) {
         if (w + 2 < NSRC) request(w + 2);
       }
     }
-    colsum[0] += (own.m == 0) ? bs : 0.f;
-    if constexpr (NOUT == 2) colsum[1] += (own.m == 1) ? bs : 0.f;
   } else {
     const char* base = xch + buf * X::BUF_B + own.src0 * X::SLOT_B + lane * (int)sizeof(typename P::frag);
+    (void)ba; (void)layer;
     typename P::frag fa[NSRC][P::S32], fb[NSRC][P::S32];
     constexpr bool kAllAtOnce = (P::ELEMS == 8);  // bf16: 16 x 4 VGPRs in flight; f32: per source (16 + 16 VGPRs)
     if (kAllAtOnce) {
@@ -915,6 +1091,7 @@ __device__ __forceinline__ void xch_take(char* xch, int& buf, int lane, int wv, 
     }
   }
   buf ^= 1;
+  pc.mark(ph + 2);  // owner reads + MFMAs (+ the bf16 epilogue in their shadow)
 }
 
 // dZ = mask(dX) of the dense just issued (mask_frags), and the owner half of the PREVIOUS layer's exchange (xch_take).
@@ -922,26 +1099,24 @@ __device__ __forceinline__ void xch_take(char* xch, int& buf, int lane, int wv, 
 template <class P, int NT, int NIN, int NOUT>
 __device__ __forceinline__ void mask_take(f32x16 (&a)[NT], const typename P::frag (&h)[NT * P::S32],
                                           typename P::frag (&out)[NT * P::S32], char* xch, int& buf, int lane, int wv,
-                                          f32x16& acc, float* colsum) {
+                                          f32x16& acc, BiasAcc& ba, int layer, PhaseClock& pc, int ph) {
   if constexpr (P::ELEMS == 8 && HBR_XCH_TR && HBR_K4_INTERLEAVE) {
     constexpr int WORDS = NT * P::S32 * 4;
     uint32_t ow[WORDS];
     uint32_t ones = 0x00010001u;
     asm volatile("" : "+v"(ones));
-    xch_take<P, NIN, NOUT, WORDS>(xch, buf, lane, wv, acc, colsum, [&](int k) {
+    xch_take<P, NIN, NOUT, WORDS>(xch, buf, lane, wv, acc, ba, layer, pc, ph, [&](int k) {
       const int f = k >> 2, t = f / P::S32, s = f % P::S32, j = k & 3;
       const uint32_t g = pack_bf16x2(a[t][8 * s + 2 * j], a[t][8 * s + 2 * j + 1]);
       ow[k] = pk_keep_where_nonzero_ordered(g, __builtin_bit_cast(u32x4, h[f])[j], ones);
     });
 #pragma unroll
     for (int f = 0; f < NT * P::S32; ++f) {
-      u32x4 w;
-      w[0] = ow[4 * f]; w[1] = ow[4 * f + 1]; w[2] = ow[4 * f + 2]; w[3] = ow[4 * f + 3];
-      out[f] = __builtin_bit_cast(bf16x8, w);
+      out[f] = PBf16::from_words(ow[4 * f], ow[4 * f + 1], ow[4 * f + 2], ow[4 * f + 3]);
     }
   } else {
     mask_frags<P, NT>(a, h, out);
-    xch_take<P, NIN, NOUT>(xch, buf, lane, wv, acc, colsum);
+    xch_take<P, NIN, NOUT>(xch, buf, lane, wv, acc, ba, layer, pc, ph);
   }
 }
 
@@ -960,7 +1135,9 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
   __syncthreads();
   const char* img = WLDS ? (const char*)limg : gimg;
   const float* bias = (const float*)(img + T::BIAS_OFF_ALL);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5;
+  // the wave index as a SCALAR: which dW tile a wave owns, which sources it sums and where it reads them from are then
+  // wave-uniform by construction - scalar branches (no EXEC masking around the owner MFMAs) and scalar address terms
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h = lane >> 5;
   const uint32_t ntiles = (fs.N + 31) / 32;
   const uint32_t stride = gridDim.x * 4;
   const uint32_t rounds = (ntiles + stride - 1) / stride;  // every wave runs every round: the barriers are workgroup-wide
@@ -975,29 +1152,29 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
   uint32_t amax[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) amax[i] = 0u;
-  float bsum[10];
+  float bsum[10];  // f32: the lane's bias-gradient partials (xch_put); bf16: filled from `ba` at the end
 #pragma unroll
   for (int i = 0; i < 10; ++i) bsum[i] = 0.f;
+  BiasAcc ba;
+  ba.init(lane);
   int buf = 0;
 
   TileIn nxt;
-  {
-    const uint32_t t0 = blockIdx.x * 4 + wv;
-    const uint32_t n0 = t0 * 32 + (lane & 31);
-    load_tile_in<LAYOUT, DT, true>(fs, ps, dout, n0, t0 < ntiles && n0 < fs.N, h, nxt);
-  }
+  TileCursor ahead;  // the tile being prefetched
+  ahead.start((blockIdx.x * 4 + wv) * 32 + (lane & 31), stride * 32, ps.group);
+  load_tile_in<LAYOUT, DT, true>(fs, ps, dout, ahead, ahead.n < fs.N, h, nxt);
+  PhaseClock pc;
+  pc.start();
   for (uint32_t r = 0; r < rounds; ++r) {
     const uint32_t tile = blockIdx.x * 4 + wv + r * stride;
     const uint32_t n = tile * 32 + (lane & 31);
     const bool valid = tile < ntiles && n < fs.N;
     const TileIn cur = nxt;
-    {
-      const uint32_t tn = tile + stride;
-      const uint32_t nn = tn * 32 + (lane & 31);
-      load_tile_in<LAYOUT, DT, true>(fs, ps, dout, nn, tn < ntiles && nn < fs.N, h, nxt);
-    }
+    ahead.advance();  // n < N implies its tile exists; N < 2^31 and at most one round past the end: no wrap-around
+    load_tile_in<LAYOUT, DT, true>(fs, ps, dout, ahead, ahead.n < fs.N, h, nxt);
     Saved<P> sv;
-    forward_tile<P, DT>(img, bias, cur, lane, sv);
+    pc.mark(0);  // next tile's loads issued
+    forward_tile<P, DT, true>(img, bias, cur, lane, sv, pc);
     const int lofs = opaque_lane_offset<P>(lane);
     const float4 dO = cur.dO;  // zero on invalid lanes => every dZ of such a point is zero
 
@@ -1013,102 +1190,116 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
 #pragma unroll
       for (int s = 0; s < P::S8; ++s) dz3[s] = P::from_acc(a, s);
     }
-    constexpr bool kWPre = (P::ELEMS == 8) && HBR_K4_WPRE;
-    typename P::frag wpre[kPreFrags];
-    if constexpr (kWPre) dense_request<P, P::S8>(img, T::b_base(C3), lofs, wpre);
+    pc.mark(1);  // dZ of the output layer (expf)
     xch_put<P, 2, 1, 2 * P::S32, P::S8>(xch, buf, lane, wv, sv.c2, dz3, bsum + db_base(C3));  // take: after the next layer's dense
     // ---- C2
     typename P::frag dzc2[2 * P::S32];
     {
       f32x16 a[2];
-      if constexpr (kWPre) dense_requested<P, 2, P::S8>(img, T::b_base(C3), lofs, wpre, dz3, a);
-      else dense<P, 2, P::S8, false>(img, T::b_base(C3), nullptr, lane, lofs, dz3, a);
-      mask_take<P, 2, 2, 1>(a, sv.c2, dzc2, xch, buf, lane, wv, acc[C3], bsum + db_base(C3));
+      dense<P, 2, P::S8, 0>(img, T::b_base(C3), nullptr, lane, lofs, dz3, a);
+      mask_take<P, 2, 2, 1>(a, sv.c2, dzc2, xch, buf, lane, wv, acc[C3], ba, C3, pc, 2);
     }
-    if constexpr (kWPre) dense_request<P, 2 * P::S32>(img, T::b_base(C2), lofs, wpre);
     xch_put<P, 2, 2, 2 * P::S32, 2 * P::S32>(xch, buf, lane, wv, sv.c1, dzc2, bsum + db_base(C2));  // take: after the next layer's dense
     // ---- C1
     typename P::frag dzc1[2 * P::S32];
     {
       f32x16 a[2];
-      if constexpr (kWPre) dense_requested<P, 2, 2 * P::S32>(img, T::b_base(C2), lofs, wpre, dzc2, a);
-      else dense<P, 2, 2 * P::S32, false>(img, T::b_base(C2), nullptr, lane, lofs, dzc2, a);
-      mask_take<P, 2, 2, 2>(a, sv.c1, dzc1, xch, buf, lane, wv, acc[C2], bsum + db_base(C2));
+      dense<P, 2, 2 * P::S32, 0>(img, T::b_base(C2), nullptr, lane, lofs, dzc2, a);
+      mask_take<P, 2, 2, 2>(a, sv.c1, dzc1, xch, buf, lane, wv, acc[C2], ba, C2, pc, 5);
     }
-    if constexpr (kWPre) dense_request<P, 2 * P::S32>(img, T::b_base(C1), lofs, wpre);
     xch_put<P, 2, 2, P::S32 + P::S8, 2 * P::S32>(xch, buf, lane, wv, sv.cin, dzc1, bsum + db_base(C1));  // take: after the next layer's dense
     // ---- L3: ds rows 1..15 = d cin slots 1..15 ; row 0 = d sigma * lrelu'(s0)
     typename P::frag dz_s[P::S16];
     {
       f32x16 a[1];
-      if constexpr (kWPre) dense_requested<P, 1, 2 * P::S32>(img, T::b_base(C1), lofs, wpre, dzc1, a);
-      else dense<P, 1, 2 * P::S32, false>(img, T::b_base(C1), nullptr, lane, lofs, dzc1, a);
+      dense<P, 1, 2 * P::S32, 0>(img, T::b_base(C1), nullptr, lane, lofs, dzc1, a);
       if (h == 0) a[0][0] = dO.w * (sv.s0 > 0.f ? 1.f : 0.01f);
 #pragma unroll
       for (int s = 0; s < P::S16; ++s) dz_s[s] = P::from_acc(a[0], s);
     }
-    xch_take<P, 2, 2>(xch, buf, lane, wv, acc[C1], bsum + db_base(C1));
-    if constexpr (kWPre) dense_request<P, P::S16>(img, T::b_base(L3), lofs, wpre);
+    xch_take<P, 2, 2>(xch, buf, lane, wv, acc[C1], ba, C1, pc, 8);
     xch_put<P, 2, 1, 2 * P::S32, P::S16>(xch, buf, lane, wv, sv.h2, dz_s, bsum + db_base(L3));  // take: after the next layer's dense
     // ---- L2
     typename P::frag dz2[2 * P::S32];
     {
       f32x16 a[2];
-      if constexpr (kWPre) dense_requested<P, 2, P::S16>(img, T::b_base(L3), lofs, wpre, dz_s, a);
-      else dense<P, 2, P::S16, false>(img, T::b_base(L3), nullptr, lane, lofs, dz_s, a);
-      mask_take<P, 2, 2, 1>(a, sv.h2, dz2, xch, buf, lane, wv, acc[L3], bsum + db_base(L3));
+      dense<P, 2, P::S16, 0>(img, T::b_base(L3), nullptr, lane, lofs, dz_s, a);
+      mask_take<P, 2, 2, 1>(a, sv.h2, dz2, xch, buf, lane, wv, acc[L3], ba, L3, pc, 11);
     }
-    if constexpr (kWPre) dense_request<P, 2 * P::S32>(img, T::b_base(L2), lofs, wpre);
     xch_put<P, 2, 2, 2 * P::S32, 2 * P::S32>(xch, buf, lane, wv, sv.h1, dz2, bsum + db_base(L2));  // take: after the next layer's dense
     // ---- L1
     typename P::frag dz1[2 * P::S32];
     {
       f32x16 a[2];
-      if constexpr (kWPre) dense_requested<P, 2, 2 * P::S32>(img, T::b_base(L2), lofs, wpre, dz2, a);
-      else dense<P, 2, 2 * P::S32, false>(img, T::b_base(L2), nullptr, lane, lofs, dz2, a);
-      mask_take<P, 2, 2, 2>(a, sv.h1, dz1, xch, buf, lane, wv, acc[L2], bsum + db_base(L2));
+      dense<P, 2, 2 * P::S32, 0>(img, T::b_base(L2), nullptr, lane, lofs, dz2, a);
+      mask_take<P, 2, 2, 2>(a, sv.h1, dz1, xch, buf, lane, wv, acc[L2], ba, L2, pc, 14);
     }
-    if constexpr (kWPre) dense_request<P, 2 * P::S32>(img, T::b_base(L1), lofs, wpre);
     xch_put<P, 1, 2, P::S32, 2 * P::S32>(xch, buf, lane, wv, sv.x0, dz1, bsum + db_base(L1));  // take: after the next layer's dense
     // ---- d feat
     if (dfd.p) {
       f32x16 a[1];
-      if constexpr (kWPre) dense_requested<P, 1, 2 * P::S32>(img, T::b_base(L1), lofs, wpre, dz1, a);
-      else dense<P, 1, 2 * P::S32, false>(img, T::b_base(L1), nullptr, lane, lofs, dz1, a);
+      dense<P, 1, 2 * P::S32, 0>(img, T::b_base(L1), nullptr, lane, lofs, dz1, a);
       if (valid) {
+        constexpr int ES = DT == HBR_F32 ? 8 : 4;
+        const uint32_t off = planar_off<ES>(fs.N, n, h);  // the offset this tile's features were loaded from
+        // words to store per level pair: fp32 (v0,v1),(v2,v3); bf16 the packed pairs.  The maxima are of the values AS
+        // STORED; bf16 keeps them per 16-bit half (both halves of a word belong to one level).
+        auto emit = [&](auto fast_tag) {
+          constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float v0 = a[0][4 * g], v1 = a[0][4 * g + 1], v2 = a[0][4 * g + 2], v3 = a[0][4 * g + 3];
-          const int lvl = 4 * g + 2 * h;
-          if (DT == HBR_F32) {
-            amax[2 * g] = max(amax[2 * g], max(__float_as_uint(v0) & 0x7fffffffu, __float_as_uint(v1) & 0x7fffffffu));
-            amax[2 * g + 1] = max(amax[2 * g + 1], max(__float_as_uint(v2) & 0x7fffffffu, __float_as_uint(v3) & 0x7fffffffu));
-            if (LAYOUT == HBR_LAYOUT_PLANAR) {
-              ((float2*)dfd.p)[(size_t)lvl * fs.N + n] = make_float2(v0, v1);
-              ((float2*)dfd.p)[(size_t)(lvl + 1) * fs.N + n] = make_float2(v2, v3);
+          for (int g = 0; g < 4; ++g) {
+            const float v0 = a[0][4 * g], v1 = a[0][4 * g + 1], v2 = a[0][4 * g + 2], v3 = a[0][4 * g + 3];
+            const int lvl = 4 * g + 2 * h;
+            char* lb0 = (char*)dfd.p + planar_level_base<ES>(fs.N, 2 * g);  // wave-uniform bases of levels 4g + 2h, + 1
+            char* lb1 = (char*)dfd.p + planar_level_base<ES>(fs.N, 2 * g + 1);
+            if (DT == HBR_F32) {
+              amax[2 * g] = max(amax[2 * g], max(__float_as_uint(v0) & 0x7fffffffu, __float_as_uint(v1) & 0x7fffffffu));
+              amax[2 * g + 1] = max(amax[2 * g + 1], max(__float_as_uint(v2) & 0x7fffffffu, __float_as_uint(v3) & 0x7fffffffu));
+              if (FAST) {
+                *(float2*)(lb0 + off) = make_float2(v0, v1);
+                *(float2*)(lb1 + off) = make_float2(v2, v3);
+              } else if (LAYOUT == HBR_LAYOUT_PLANAR) {
+                ((float2*)dfd.p)[(size_t)lvl * fs.N + n] = make_float2(v0, v1);
+                ((float2*)dfd.p)[(size_t)(lvl + 1) * fs.N + n] = make_float2(v2, v3);
+              } else {
+                *(float4*)((float*)dfd.p + (size_t)n * dfd.stride + 2 * lvl) = make_float4(v0, v1, v2, v3);
+              }
             } else {
-              *(float4*)((float*)dfd.p + (size_t)n * dfd.stride + 2 * lvl) = make_float4(v0, v1, v2, v3);
-            }
-          } else {
-            const uint32_t p01 = pack_bf16x2(v0, v1), p23 = pack_bf16x2(v2, v3);  // the maxima are of the ROUNDED values
-            amax[2 * g] = max(amax[2 * g], max((p01 << 16) & 0x7fffffffu, p01 & 0x7fff0000u));
-            amax[2 * g + 1] = max(amax[2 * g + 1], max((p23 << 16) & 0x7fffffffu, p23 & 0x7fff0000u));
-            if (LAYOUT == HBR_LAYOUT_PLANAR) {
-              ((uint32_t*)dfd.p)[(size_t)lvl * fs.N + n] = p01;
-              ((uint32_t*)dfd.p)[(size_t)(lvl + 1) * fs.N + n] = p23;
-            } else {
-              *(uint2*)((uint16_t*)dfd.p + (size_t)n * dfd.stride + 2 * lvl) = make_uint2(p01, p23);
+              const uint32_t p01 = pack_bf16x2(v0, v1), p23 = pack_bf16x2(v2, v3);
+              amax[2 * g] = pk_max_u16(amax[2 * g], p01 & 0x7fff7fffu);
+              amax[2 * g + 1] = pk_max_u16(amax[2 * g + 1], p23 & 0x7fff7fffu);
+              if (FAST) {
+                *(uint32_t*)(lb0 + off) = p01;
+                *(uint32_t*)(lb1 + off) = p23;
+              } else if (LAYOUT == HBR_LAYOUT_PLANAR) {
+                ((uint32_t*)dfd.p)[(size_t)lvl * fs.N + n] = p01;
+                ((uint32_t*)dfd.p)[(size_t)(lvl + 1) * fs.N + n] = p23;
+              } else {
+                *(uint2*)((uint16_t*)dfd.p + (size_t)n * dfd.stride + 2 * lvl) = make_uint2(p01, p23);
+              }
             }
           }
-        }
+        };
+        if (LAYOUT == HBR_LAYOUT_PLANAR && fs.addr32) emit(std::true_type{});
+        else emit(std::false_type{});
       }
     }
-    xch_take<P, 1, 2>(xch, buf, lane, wv, acc[L1], bsum + db_base(L1));
+    xch_take<P, 1, 2>(xch, buf, lane, wv, acc[L1], ba, L1, pc, 17);
   }
 
+  pc.finish();
   // ---- flush: every wave parks its registers in the workgroup's slab (plain coalesced stores; mlp_dw_reduce_kernel
   // turns the slabs into parameter gradients)
   asm volatile("s_nop 15" ::: "memory");  // last asm MFMA's D -> first VALU reader
+  if constexpr (P::ELEMS == 8 && HBR_XCH_TR) {  // layer l, out tile own.m: register l of the lower lane half
+    auto park = [&](int l, int m, int nout) {
+      const float v = h ? 0.f : ba.tile[l];
+      bsum[db_base(l)] = (m == 0) ? v : 0.f;
+      if (nout == 2) bsum[db_base(l) + 1] = (m == 1) ? v : 0.f;
+    };
+    park(L1, Own<1, 2>(wv).m, 2); park(L2, Own<2, 2>(wv).m, 2); park(L3, Own<2, 1>(wv).m, 1);
+    park(C1, Own<2, 2>(wv).m, 2); park(C2, Own<2, 2>(wv).m, 2); park(C3, Own<2, 1>(wv).m, 1);
+  }
   float* mine = slabs + ((size_t)blockIdx.x * 4 + wv) * kSlabWave + lane;
 #pragma unroll
   for (int l = 0; l < NLAYER; ++l)
@@ -1117,6 +1308,10 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
 #pragma unroll
   for (int i = 0; i < 10; ++i) mine[(NLAYER * 16 + i) * 64] = bsum[i];
   if (dfd.abs_part) {  // the wave's maxima: reduce over the 32 lanes of each half, lanes 0 and 32 store their 8 levels
+    if (DT == HBR_BF16) {  // two bf16 maxima per register -> the fp32 bit pattern of the larger
+#pragma unroll
+      for (int i = 0; i < 8; ++i) amax[i] = max(amax[i] << 16, amax[i] & 0xffff0000u);
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
 #pragma unroll
@@ -1184,8 +1379,8 @@ static int launch_bwd_fused(uint32_t ntiles, hipStream_t st, const char* img, Fe
   if (rc) return rc;
   float* tot = slabs + (size_t)kMaxBwdBlocks * kSlabWg + 16 * (size_t)kAbsWaves;  // behind the maxima
   hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(kSlabWg / 32 + (want_abs ? 16 : 0)), dim3(256), 0, st, (const float*)slabs, (int)blocks,
-                     tot, (const uint32_t*)dfd.abs_part, absmax_out);
-  hipLaunchKernelGGL(mlp_dw_finalize_kernel, dim3((kSlabWg + 255) / 256), dim3(256), 0, st, (const float*)tot, dparams);
+                     tot, (const uint32_t*)dfd.abs_part, absmax_out, kXchSwapped<P>);
+  hipLaunchKernelGGL(mlp_dw_finalize_kernel, dim3((kSlabWg + 255) / 256), dim3(256), 0, st, (const float*)tot, dparams, kXchSwapped<P>);
   return HBR_OK;
 }
 
@@ -1195,6 +1390,13 @@ static int launch_bwd(int precision, uint32_t ntiles, hipStream_t st, const char
                       DFeatDst dfd, float* dparams, float* absmax_out) {
   if (precision == HBR_BF16) return launch_bwd_fused<PBf16, LAYOUT, DT, true>(ntiles, st, img, fs, ps, dout, dfd, dparams, absmax_out);
   return launch_bwd_fused<PF32, LAYOUT, DT, false>(ntiles, st, img, fs, ps, dout, dfd, dparams, absmax_out);
+}
+
+// HBR_MLP_ADDR64 (any value) in the environment sends every call down the 64-bit addressing path that sizes beyond
+// kAddr32MaxN take - the tests use it to cover that path at small sizes
+static uint32_t addr32_ok(int64_t N, int64_t group) {
+  static const bool force64 = getenv("HBR_MLP_ADDR64") != nullptr;
+  return (!force64 && N <= kAddr32MaxN && N / group <= kAddr32MaxRays) ? 1u : 0u;
 }
 
 static int check_common(const void* feat, int layout, int64_t stride, int dt, const float* pe, int64_t N, int64_t group,
@@ -1215,6 +1417,17 @@ static int check_common(const void* feat, int layout, int64_t stride, int dt, co
 
 using namespace hbr;
 using namespace hbr::mlp;
+
+#if HBR_K4_PROF
+extern "C" int hbr_debug_k4_prof(unsigned long long* out64, int reset) {  // development builds only
+  if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(k4_prof), sizeof(unsigned long long) * 64) != hipSuccess) return HBR_EINVAL;
+  if (reset) {
+    unsigned long long z[64] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(k4_prof), z, sizeof(z)) != hipSuccess) return HBR_EINVAL;
+  }
+  return HBR_OK;
+}
+#endif
 
 extern "C" int64_t hbr_mlp_workspace_bytes(int precision) {
   // the MFMA-fragment image of the weights, then (backward only) one weight-gradient slab per workgroup
@@ -1241,7 +1454,7 @@ extern "C" int hbr_mlp_fwd(const void* feat, int layout, int64_t feat_stride, in
   if (!out || ((uintptr_t)out & 15)) return HBR_EINVAL;
   if (N == 0) return HBR_OK;
   hipStream_t st = (hipStream_t)stream;
-  FeatSrc fs{feat, feat_stride, (uint32_t)N};
+  FeatSrc fs{feat, feat_stride, (uint32_t)N, addr32_ok(N, group)};
   PeSrc ps{viewdirs_enc, (uint32_t)group};
   const uint32_t ntiles = (uint32_t)((N + 31) / 32);
   uint32_t blocks = (ntiles + kFwdWaves - 1) / kFwdWaves;
@@ -1269,7 +1482,7 @@ extern "C" int hbr_mlp_bwd(const void* feat, int layout, int64_t feat_stride, in
   if (!dout || !dparams || ((uintptr_t)dout & 15)) return HBR_EINVAL;
   if (N == 0) return HBR_OK;
   hipStream_t st = (hipStream_t)stream;
-  FeatSrc fs{feat, feat_stride, (uint32_t)N};
+  FeatSrc fs{feat, feat_stride, (uint32_t)N, addr32_ok(N, group)};
   PeSrc ps{viewdirs_enc, (uint32_t)group};
   DFeatDst dfd{dfeat, feat_stride, nullptr};
   const uint32_t ntiles = (uint32_t)((N + 31) / 32);

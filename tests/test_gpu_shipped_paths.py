@@ -386,3 +386,87 @@ def test_k2_lds_kernels_edge_shapes_vs_oracle(ops, T, layout, dt, outside):
     again = torch.zeros_like(got)
     ops.hash_encode_bwd(geom, dyd, again, x=x.to(DEV), layout=ROWS if layout == "rows" else PLANAR, algo=2)
     assert torch.equal(again, got)
+
+
+_ADDR_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/oracle")
+import ref_cpu
+from hbr_amd import ops
+from hbr_amd._lib import BF16, F32, PLANAR
+dev = "cuda:0"
+g = torch.Generator().manual_seed(11)
+R, S = 37, 29                      # N = 1073: partial last tile, several points per ray
+N = R * S
+_, d, _, _ = ref_cpu.synthetic_rays(R, seed=3)
+pe = ops.dir_encode(d.to(dev), 4)
+P = torch.cat([v.reshape(-1) for v in ref_cpu.mlp_init(5).values()]).to(dev)
+feat = (torch.randn((16, N, 2), generator=g) * 0.3)
+dout = torch.randn((N, 4), generator=g).to(dev)
+res = {}
+for name, fdt, prec in (("bf16", torch.bfloat16, BF16), ("f32", torch.float32, F32)):
+    f = feat.to(fdt).to(dev)
+    out = ops.mlp_fwd(f, PLANAR, pe, S, P, prec)
+    dP = torch.zeros_like(P); amax = torch.zeros(16, device=dev)
+    df = ops.mlp_bwd(f, PLANAR, pe, S, P, prec, dout, dP, absmax_out=amax)
+    res[name + "_out"] = out.cpu().numpy(); res[name + "_dP"] = dP.cpu().numpy()
+    res[name + "_df"] = df.float().cpu().numpy(); res[name + "_amax"] = amax.cpu().numpy()
+np.savez(sys.argv[2], **res)
+"""
+
+
+def test_mlp_64bit_addressing_path_equals_32bit_path(tmp_path):
+    """Beyond 2^27 points (or 2^25 rays) the MLP kernels switch from 32-bit offsets off wave-uniform level bases to
+    64-bit per-lane addresses and a division for the ray index.  HBR_MLP_ADDR64 forces that path at a small size (in a
+    child process: the knob is read once per process); every output must equal the default path's bit for bit."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    outs = {}
+    for tag, extra in (("a32", {}), ("a64", {"HBR_MLP_ADDR64": "1"})):
+        env = dict(os.environ, **extra)
+        env.pop("HBR_MLP_ADDR64", None) if not extra else None
+        path = str(tmp_path / f"{tag}.npz")
+        r = subprocess.run([sys.executable, "-c", _ADDR_SCRIPT, ROOT, path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = np.load(path)
+    assert set(outs["a32"].files) == set(outs["a64"].files) and len(outs["a32"].files) == 8
+    for k in outs["a32"].files:
+        assert np.array_equal(outs["a32"][k], outs["a64"][k]), k
+    assert np.abs(outs["a32"]["bf16_df"]).max() > 0 and np.abs(outs["a32"]["f32_dP"]).max() > 0
+
+
+@pytest.mark.parametrize("precision", [1, 0])
+def test_mlp_instantiations_agree_bit_for_bit(ops, precision):
+    """The MLP kernels are compiled once per (feature layout, feature storage type); all of them run the same
+    arithmetic, so on features that are exactly representable in bf16 every instantiation must return the same bits
+    (outputs, parameter gradients, per-level maxima; feature gradients after rounding the fp32-stored ones to bf16).
+    Guards against per-instantiation code-generation accidents: a scheduling-dependent wrong result in ONE of them
+    (rows layout, fp32 features, bf16 MFMA) is what this test was written after."""
+    from hbr_amd._lib import PLANAR
+    g = torch.Generator().manual_seed(23)
+    R, S = 41, 27                     # N = 1107: a partial last tile
+    N = R * S
+    _, d, _, _ = ref_cpu.synthetic_rays(R, seed=4)
+    pe = ops.dir_encode(d.to(DEV), 4)
+    P = torch.cat([v.reshape(-1) for v in ref_cpu.mlp_init(9).values()]).to(DEV)
+    feat = (torch.randn((N, 32), generator=g) * 0.3).bfloat16()
+    dout = torch.randn((N, 4), generator=g).to(DEV)
+    got = {}
+    for lay in (0, PLANAR):
+        for fdt in (torch.float32, torch.bfloat16):
+            f = feat.to(fdt)
+            f = (f.reshape(N, 16, 2).permute(1, 0, 2) if lay == PLANAR else f).contiguous().to(DEV)
+            out = ops.mlp_fwd(f, lay, pe, S, P, precision)
+            dP = torch.zeros_like(P)
+            amax = torch.zeros(16, device=DEV)
+            df = ops.mlp_bwd(f, lay, pe, S, P, precision, dout, dP, absmax_out=amax)
+            df = (df.permute(1, 0, 2).reshape(N, 32) if lay == PLANAR else df)
+            got[(lay, fdt)] = (out.cpu(), dP.cpu(), df.bfloat16().cpu(), amax.cpu() if fdt == torch.bfloat16 else None)
+    ref = got[(PLANAR, torch.bfloat16)]
+    assert float(ref[1].abs().max()) > 0 and float(ref[2].float().abs().max()) > 0
+    for key, (out, dP, df, amax) in got.items():
+        assert torch.equal(out, ref[0]), ("out", key)
+        assert torch.equal(dP, ref[1]), ("dparams", key)
+        assert torch.equal(df, ref[2]), ("dfeat", key)
+        if amax is not None:
+            assert torch.equal(amax, ref[3]), ("absmax", key)

@@ -31,7 +31,7 @@ def test_header_symbols_all_exported(L):
     assert lib.hbr_strerror(-2).decode().startswith("configuration not supported")
     # MFMA-fragment image of the weights (34 KiB forward + 28 KiB backward + 6 x 64 biases), then one weight-gradient
     # slab per backward workgroup: 256 workgroups x 4 waves x (6 tiles x 16 + 10 bias) registers x 64 lanes x 4 B
-    img = (34 + 28) * 1024 + 6 * 64 * 4
+    img = (34 + 10 + 28) * 1024 + 6 * 64 * 4  # 10: one bias k-step per forward output tile
     assert img % 256 == 0
     # ... the per-wave feature-gradient maxima of the backward (16 levels x 1024 waves x 4 B) and one slab of totals
     slabs = 256 * 4 * (6 * 16 + 10) * 64 * 4 + 16 * 1024 * 4 + 4 * (6 * 16 + 10) * 64 * 4
