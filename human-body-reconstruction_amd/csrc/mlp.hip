@@ -589,60 +589,66 @@ struct Saved {
 };
 
 
-// DT: storage type of the feature buffer the tile was loaded from.  BSTEP: bf16 bias by the extra k-step (the backward
+// One layer of the forward chain on the fragments saved so far.  BSTEP: bf16 bias by the extra k-step (the backward
 // kernel: 40 fewer LDS reads and 32 fewer live registers per tile) or read into the accumulators (the forward kernel,
-// which has the occupancy to hide those reads and is 10 % faster without the ten extra MFMAs)
-template <class P, int DT, bool BSTEP>
-__device__ __forceinline__ void forward_tile(const char* img, const float* bias, const TileIn& ti, int lane, Saved<P>& sv,
-                                             PhaseClock& pc) {
+// which has the occupancy to hide those reads and is 10 % faster without the ten extra MFMAs).
+template <class P, bool BSTEP, int LAYER>
+__device__ __forceinline__ void forward_layer(const char* img, const float* bias, int lane, int lofs, float4 peA, float4 peB,
+                                              float4 peC, Saved<P>& sv, PhaseClock& pc) {
   using T = Tab<P>;
-  const int h = lane >> 5;
-  const int lofs = opaque_lane_offset<P>(lane);
-  feat_frags<P, DT>(ti, sv.x0);
-  pc.mark_after(20, sv.x0[P::S32 - 1]);  // the tile's inputs have arrived
-  const float4 peA = ti.peA, peB = ti.peB, peC = ti.peC;
-  {
+  constexpr int B = BSTEP ? 2 : 1;
+  if constexpr (LAYER == L1) {
     f32x16 a[2];
-    dense<P, 2, P::S32, (BSTEP ? 2 : 1)>(img, T::f_base(L1), bias + 64 * L1, lane, lofs, sv.x0, a);
+    dense<P, 2, P::S32, B>(img, T::f_base(L1), bias + 64 * L1, lane, lofs, sv.x0, a);
     pc.mark_after(21, a[1]);
     relu_frags<P, 2>(a, sv.h1);
     pc.mark_after(22, sv.h1[2 * P::S32 - 1]);
-  }
-  {
+  } else if constexpr (LAYER == L2) {
     f32x16 a[2];
-    dense<P, 2, 2 * P::S32, (BSTEP ? 2 : 1)>(img, T::f_base(L2), bias + 64 * L2, lane, lofs, sv.h1, a);
+    dense<P, 2, 2 * P::S32, B>(img, T::f_base(L2), bias + 64 * L2, lane, lofs, sv.h1, a);
     pc.mark_after(23, a[1]);
     relu_frags<P, 2>(a, sv.h2);
     pc.mark_after(24, sv.h2[2 * P::S32 - 1]);
-  }
-  {
+  } else if constexpr (LAYER == L3) {
     f32x16 a[1];
-    dense<P, 1, 2 * P::S32, (BSTEP ? 2 : 1)>(img, T::f_base(L3), bias + 64 * L3, lane, lofs, sv.h2, a);
+    dense<P, 1, 2 * P::S32, B>(img, T::f_base(L3), bias + 64 * L3, lane, lofs, sv.h2, a);
     pc.mark_after(25, a[0]);
     sv.s0 = a[0][0];
     P::cin(a[0], peA, peB, peC, sv.cin);
     pc.mark_after(26, sv.cin[P::S32 + P::S8 - 1]);
-  }
-  {
+  } else if constexpr (LAYER == C1) {
     f32x16 a[2];
-    dense<P, 2, P::S32 + P::S8, (BSTEP ? 2 : 1)>(img, T::f_base(C1), bias + 64 * C1, lane, lofs, sv.cin, a);
+    dense<P, 2, P::S32 + P::S8, B>(img, T::f_base(C1), bias + 64 * C1, lane, lofs, sv.cin, a);
     pc.mark_after(27, a[1]);
     relu_frags<P, 2>(a, sv.c1);
     pc.mark_after(28, sv.c1[2 * P::S32 - 1]);
-  }
-  {
+  } else if constexpr (LAYER == C2) {
     f32x16 a[2];
-    dense<P, 2, 2 * P::S32, (BSTEP ? 2 : 1)>(img, T::f_base(C2), bias + 64 * C2, lane, lofs, sv.c1, a);
+    dense<P, 2, 2 * P::S32, B>(img, T::f_base(C2), bias + 64 * C2, lane, lofs, sv.c1, a);
     pc.mark_after(29, a[1]);
     relu_frags<P, 2>(a, sv.c2);
     pc.mark_after(30, sv.c2[2 * P::S32 - 1]);
-  }
-  {
+  } else {
     f32x16 a[1];
-    dense<P, 1, 2 * P::S32, (BSTEP ? 2 : 1)>(img, T::f_base(C3), bias + 64 * C3, lane, lofs, sv.c2, a);
+    dense<P, 1, 2 * P::S32, B>(img, T::f_base(C3), bias + 64 * C3, lane, lofs, sv.c2, a);
     pc.mark_after(31, a[0]);
     sv.raw[0] = a[0][0]; sv.raw[1] = a[0][1]; sv.raw[2] = a[0][2];
   }
+}
+
+// DT: storage type of the feature buffer the tile was loaded from
+template <class P, int DT, bool BSTEP>
+__device__ __forceinline__ void forward_tile(const char* img, const float* bias, const TileIn& ti, int lane, Saved<P>& sv,
+                                             PhaseClock& pc) {
+  const int lofs = opaque_lane_offset<P>(lane);
+  feat_frags<P, DT>(ti, sv.x0);
+  pc.mark_after(20, sv.x0[P::S32 - 1]);  // the tile's inputs have arrived
+  forward_layer<P, BSTEP, L1>(img, bias, lane, lofs, ti.peA, ti.peB, ti.peC, sv, pc);
+  forward_layer<P, BSTEP, L2>(img, bias, lane, lofs, ti.peA, ti.peB, ti.peC, sv, pc);
+  forward_layer<P, BSTEP, L3>(img, bias, lane, lofs, ti.peA, ti.peB, ti.peC, sv, pc);
+  forward_layer<P, BSTEP, C1>(img, bias, lane, lofs, ti.peA, ti.peB, ti.peC, sv, pc);
+  forward_layer<P, BSTEP, C2>(img, bias, lane, lofs, ti.peA, ti.peB, ti.peC, sv, pc);
+  forward_layer<P, BSTEP, C3>(img, bias, lane, lofs, ti.peA, ti.peB, ti.peC, sv, pc);
 }
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }          // test_hash.py:38,67
@@ -1172,8 +1178,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
     const TileIn cur = nxt;
     ahead.advance();  // n < N implies its tile exists; N < 2^31 and at most one round past the end: no wrap-around
     load_tile_in<LAYOUT, DT, true>(fs, ps, dout, ahead, ahead.n < fs.N, h, nxt);
-    Saved<P> sv;
     pc.mark(0);  // next tile's loads issued
+    Saved<P> sv;
     forward_tile<P, DT, true>(img, bias, cur, lane, sv, pc);
     const int lofs = opaque_lane_offset<P>(lane);
     const float4 dO = cur.dO;  // zero on invalid lanes => every dZ of such a point is zero
