@@ -84,17 +84,11 @@ struct PBf16 {
   // accumulate into a tile that lives in the accumulator (AGPR) half of the register file for the whole kernel.
   // Inline asm because the build forces the VGPR form on the builtin MFMAs (the chain's results are read by VALU code
   // right away); these dW tiles are only ever touched by the next MFMA, so keeping them in AGPRs costs no moves.
-  // `s_nop 1`: wait states between the VALU (v_cvt_pk) writes of a/b and an MFMA reading them, which hipcc does not
-  // insert inside an asm statement (cdna_hip_programming.md 5.7 item 2).
-  __device__ static __forceinline__ void mfma_acc(frag a, frag b, f32x16& c) {
-    asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-  }
-  // same, pinned in program order relative to the other volatile statements (xch_take slots VALU work behind each one)
-  __device__ static __forceinline__ void mfma_acc_ordered(frag a, frag b, f32x16& c) {
-    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-  }
-  // operands that came straight from LDS reads (no VALU write in front of the MFMA): no wait states needed, and an
-  // s_nop costs a 4-cycle issue slot at one wave per SIMD
+  // PAD: `s_nop 1` = the wait states between a VALU write of a/b (a v_mov the compiler may have placed) and the MFMA
+  // reading them, which hipcc does not insert inside an asm statement (cdna_hip_programming.md 5.7 item 2); operands
+  // that came straight from LDS reads need none, and an s_nop costs a 4-cycle issue slot at one wave per SIMD.
+  // ORDERED: volatile, i.e. pinned in program order relative to the other volatile statements (xch_take slots VALU
+  // work behind each MFMA).
   template <bool ORDERED, bool PAD>
   __device__ static __forceinline__ void mfma_acc_lds(frag a, frag b, f32x16& c) {
     if constexpr (PAD) {
@@ -118,11 +112,6 @@ struct PBf16 {
                       pack_bf16x2(acc[8 * s + 4], acc[8 * s + 5]), pack_bf16x2(acc[8 * s + 6], acc[8 * s + 7]));
   }
   __device__ static __forceinline__ frag zero() { return from_words(0u, 0u, 0u, 0u); }
-  __device__ static __forceinline__ frag ident(int s, int lane) {
-    const int r = lane & 31, h = lane >> 5;
-    auto pair = [&](int j) { return (r == rho(s, h, j) ? 0x3f80u : 0u) | (r == rho(s, h, j + 1) ? 0x3f800000u : 0u); };
-    return from_words(pair(0), pair(2), pair(4), pair(6));
-  }
   // the three k-steps of the colour net's first layer: L3 tile rows 0..15, PE 0..15, PE 16..23
   __device__ static __forceinline__ void cin(const f32x16& acc3, float4 peA, float4 peB, float4 peC, frag (&out)[3]) {
     out[0] = from_acc(acc3, 0);
@@ -168,15 +157,12 @@ struct PF32 {
 // k-step: a weight fragment whose k = 0, 1, 2 columns hold the bias split into three bf16 parts (hi + mid + lo
 // reproduces the fp32 value to 2^-24 relative), multiplied by an activation fragment that is 1 on those k and 0
 // elsewhere: 1 KiB and one MFMA per tile, accumulators start from the inline constant 0.
-#ifndef HBR_BIAS_STEP
-#define HBR_BIAS_STEP 1
-#endif
 template <class P>
 struct Tab {
   // forward: output-feature tiles and k-steps (input slots) per layer
   __device__ __host__ static constexpr int f_out_tiles(int l) { return (l == L3 || l == C3) ? 1 : 2; }
   // bf16: the bias rides on one more k-step per output tile (BIAS_STEP) instead of being read into the accumulators
-  static constexpr bool BIAS_STEP = (P::ELEMS == 8) && HBR_BIAS_STEP;
+  static constexpr bool BIAS_STEP = (P::ELEMS == 8);
   __device__ __host__ static constexpr int f_wsteps(int l) { return l == L1 ? P::S32 : (l == C1 ? P::S32 + P::S8 : 2 * P::S32); }
   __device__ __host__ static constexpr int f_ksteps(int l) { return f_wsteps(l) + (BIAS_STEP ? 1 : 0); }
   __device__ __host__ static constexpr int f_base(int l) {
@@ -334,20 +320,14 @@ __device__ __forceinline__ uint32_t pk_relu_bf16(uint32_t w) {
   asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(w));
   return r;
 }
-// (one asm statement for the pair: between two dependent statements hipcc pads an `s_nop 0` - 4 issue cycles at one
-// wave per SIMD - because it cannot see what the second one reads)
-__device__ __forceinline__ uint32_t pk_keep_where_nonzero(uint32_t grad, uint32_t act, uint32_t ones /* 0x00010001 */) {
-  uint32_t r;
-  asm("v_pk_min_u16 %0, %2, %3\n\tv_pk_mul_lo_u16 %0, %1, %0" : "=&v"(r) : "v"(grad), "v"(act), "v"(ones));
-  return r;
-}
-
 __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
   uint32_t r;
   asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
-__device__ __forceinline__ uint32_t pk_keep_where_nonzero_ordered(uint32_t grad, uint32_t act, uint32_t ones) {
+// (one asm statement for the pair: between two dependent statements hipcc pads an `s_nop 0` - 4 issue cycles at one
+// wave per SIMD - because it cannot see what the second one reads; volatile: see mfma_acc_lds)
+__device__ __forceinline__ uint32_t pk_keep_where_nonzero_ordered(uint32_t grad, uint32_t act, uint32_t ones /* 0x00010001 */) {
   uint32_t r;
   asm volatile("v_pk_min_u16 %0, %2, %3\n\tv_pk_mul_lo_u16 %0, %1, %0" : "=&v"(r) : "v"(grad), "v"(act), "v"(ones));
   return r;
@@ -376,30 +356,17 @@ __device__ __forceinline__ void relu_frags(f32x16 (&acc)[NT], typename P::frag (
   }
 }
 
-// dZ = dX where the forward activation h was positive, else 0; then re-pack (bf16: re-pack first, mask the pairs)
+// f32: dZ = dX where the forward activation h was positive, else 0 (bf16 masks packed pairs inside mask_take)
 template <class P, int NT>
 __device__ __forceinline__ void mask_frags(f32x16 (&acc)[NT], const typename P::frag (&h)[NT * P::S32],
                                            typename P::frag (&out)[NT * P::S32]) {
+  static_assert(P::ELEMS == 1, "f32 fragments");
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    if constexpr (P::ELEMS == 8) {
-      uint32_t ones = 0x00010001u;
-      asm volatile("" : "+v"(ones));  // keep it in one VGPR (the asm operands below are VGPR-only)
 #pragma unroll
-      for (int s = 0; s < P::S32; ++s) {
-        const f32x16& a = acc[t];
-        const u32x4 hw = __builtin_bit_cast(u32x4, h[t * P::S32 + s]);
-        out[t * P::S32 + s] = PBf16::from_words(pk_keep_where_nonzero(pack_bf16x2(a[8 * s], a[8 * s + 1]), hw[0], ones),
-                                                pk_keep_where_nonzero(pack_bf16x2(a[8 * s + 2], a[8 * s + 3]), hw[1], ones),
-                                                pk_keep_where_nonzero(pack_bf16x2(a[8 * s + 4], a[8 * s + 5]), hw[2], ones),
-                                                pk_keep_where_nonzero(pack_bf16x2(a[8 * s + 6], a[8 * s + 7]), hw[3], ones));
-      }
-    } else {
+    for (int s = 0; s < P::S32; ++s) acc[t][s] = (h[t * P::S32 + s] > 0.f) ? acc[t][s] : 0.f;
 #pragma unroll
-      for (int s = 0; s < P::S32; ++s) acc[t][s] = (h[t * P::S32 + s] > 0.f) ? acc[t][s] : 0.f;
-#pragma unroll
-      for (int s = 0; s < P::S32; ++s) out[t * P::S32 + s] = P::from_acc(acc[t], s);
-    }
+    for (int s = 0; s < P::S32; ++s) out[t * P::S32 + s] = P::from_acc(acc[t], s);
   }
 }
 
@@ -852,23 +819,12 @@ __global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(const float* __res
 // layers with two give each tile to a pair of waves that split the four sources.  The exchange buffer is double-buffered, so one
 // barrier per layer suffices: a wave can only overwrite buffer b two layers later, after the next barrier, which
 // every wave reaches only after finishing its reads of b.  No LDS atomics, no second recompute of the forward.
-#ifndef HBR_K4_TAKE_HALVES
-#define HBR_K4_TAKE_HALVES 1  // bf16: the owner reads two source waves at a time (32 instead of 64 fragment registers)
-#endif
-#ifndef HBR_K4_NOP
-#define HBR_K4_NOP 1  // s_nop in front of the owner MFMAs: 2 = every one, 1 = the first after operands may have moved
-#endif
-#ifndef HBR_K4_INTERLEAVE
-#define HBR_K4_INTERLEAVE 1  // bf16: ReLU-mask epilogue word by word behind the owner MFMAs (mask_take)
-#endif
-#ifndef HBR_XCH_TR
-#define HBR_XCH_TR 1  // bf16: exchange through a [point][feature] image + ds_read_b64_tr_b16 (0: identity-MFMA transposes)
-#endif
-#ifndef HBR_XCH_W16
-#define HBR_XCH_W16 1  // bf16 image: one 16-byte write per fragment (columns in xch_feature order) instead of two 8-byte ones
-#endif
+// bf16 exchanges through a [point][feature] LDS image read back with ds_read_b64_tr_b16; f32 (no 32-bit transposing
+// read) through fragments transposed by identity MFMAs
 template <class P>
-constexpr bool kXchSwapped = (P::ELEMS == 8) && HBR_XCH_TR && HBR_XCH_W16;
+constexpr bool kXchImage = (P::ELEMS == 8);
+template <class P>
+constexpr bool kXchSwapped = kXchImage<P>;  // the image's columns are in xch_feature order (16-byte writes)
 template <class P>
 struct Xch {
   static constexpr int FRAG_B = (int)sizeof(typename P::frag) * 64;
@@ -915,37 +871,21 @@ template <class P, int NIN, int NOUT, int NKX, int NKZ>
 __device__ __forceinline__ void xch_put(char* xch, int buf, int lane, int wv, const typename P::frag (&x)[NKX],
                                         const typename P::frag (&dz)[NKZ], float* colsum) {
   using X = Xch<P>;
-  if constexpr (P::ELEMS == 8 && HBR_XCH_TR) {
+  if constexpr (kXchImage<P>) {
     static_assert(X::SLOT_B == 32 * 256, "slot = 32 point rows of 256 B");
     const int pt = lane & 31, h = lane >> 5;
     const int sw16 = 16 * (((pt & 3) << 2) | ((pt >> 2) & 3));
-    if constexpr (HBR_XCH_W16) {
-      // fragment (tile ks/2, step ks%2) = the 16 features 32n+16s..: this lane's 8 elements (features 4h.., 8+4h..)
-      // go to chunk h of the pair as one 16-byte write; the 8 lanes a write cycle serves hit 8 different chunks
-      char* mine = xch + buf * X::BUF_B + wv * X::SLOT_B + 256 * pt;
+    // fragment (tile ks/2, step ks%2) = the 16 features 32n+16s..: this lane's 8 elements (features 4h.., 8+4h..) go
+    // to chunk h of the pair as ONE 16-byte write (columns in xch_feature order); the 8 lanes a write cycle serves hit
+    // 8 different chunks.  (Two 8-byte writes with the columns in feature order cost the same: a store is priced by
+    // its source dwords.)
+    char* mine = xch + buf * X::BUF_B + wv * X::SLOT_B + 256 * pt;
 #pragma unroll
-      for (int ks = 0; ks < NKX; ++ks)
-        *(u32x4*)(mine + ((16 * (4 * (ks / 2) + 2 * (ks % 2) + h)) ^ sw16)) = __builtin_bit_cast(u32x4, x[ks]);
+    for (int ks = 0; ks < NKX; ++ks)
+      *(u32x4*)(mine + ((16 * (4 * (ks / 2) + 2 * (ks % 2) + h)) ^ sw16)) = __builtin_bit_cast(u32x4, x[ks]);
 #pragma unroll
-      for (int ks = 0; ks < NKZ; ++ks)
-        *(u32x4*)(mine + ((16 * (8 + 4 * (ks / 2) + 2 * (ks % 2) + h)) ^ sw16)) = __builtin_bit_cast(u32x4, dz[ks]);
-    } else {
-      char* mine = xch + buf * X::BUF_B + wv * X::SLOT_B + 256 * pt + 8 * h;
-#pragma unroll
-      for (int ks = 0; ks < NKX; ++ks) {  // elements 0..3 -> features 32n+16s+4h.., 4..7 -> +8: columns in feature order
-        const u32x4 w = __builtin_bit_cast(u32x4, x[ks]);
-        const int ch = 4 * (ks / 2) + 2 * (ks % 2);
-        *(uint2*)(mine + ((16 * ch) ^ sw16)) = make_uint2(w[0], w[1]);
-        *(uint2*)(mine + ((16 * (ch + 1)) ^ sw16)) = make_uint2(w[2], w[3]);
-      }
-#pragma unroll
-      for (int ks = 0; ks < NKZ; ++ks) {
-        const u32x4 w = __builtin_bit_cast(u32x4, dz[ks]);
-        const int ch = 8 + 4 * (ks / 2) + 2 * (ks % 2);
-        *(uint2*)(mine + ((16 * ch) ^ sw16)) = make_uint2(w[0], w[1]);
-        *(uint2*)(mine + ((16 * (ch + 1)) ^ sw16)) = make_uint2(w[2], w[3]);
-      }
-    }
+    for (int ks = 0; ks < NKZ; ++ks)
+      *(u32x4*)(mine + ((16 * (8 + 4 * (ks / 2) + 2 * (ks % 2) + h)) ^ sw16)) = __builtin_bit_cast(u32x4, dz[ks]);
   } else {
     typename P::frag xt[NIN][P::S32], zt[NOUT][P::S32];
     transpose_frags<P, NIN, NKX, false>(x, lane, xt);
@@ -992,15 +932,12 @@ __device__ __forceinline__ void xch_take(char* xch, int& buf, int lane, int wv, 
   using X = Xch<P>;
   using O = Own<NIN, NOUT>;
   constexpr int NSRC = O::NSRC;
-  if constexpr (!(P::ELEMS == 8 && HBR_XCH_TR)) {
-#pragma unroll
-    for (int k = 0; k < WORDS; ++k) epi(k);
-  }
+  static_assert(kXchImage<P> || WORDS == 0, "only the bf16 path takes an epilogue");
   pc.mark(ph);      // put + dense (+ the f32 epilogue)
   __syncthreads();
   pc.mark(ph + 1);  // waiting for the slowest wave
   const O own(wv);
-  if constexpr (P::ELEMS == 8 && HBR_XCH_TR) {
+  if constexpr (kXchImage<P>) {
     // lane (group g of its half, q, p) supplies row q, columns 4p..4p+3 of its group's 4-point x 16-feature block
     const int h = lane >> 5, g = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
     const char* src = xch + buf * X::BUF_B + own.src0 * X::SLOT_B + 8 * (p & 1);
@@ -1024,10 +961,9 @@ __device__ __forceinline__ void xch_take(char* xch, int& buf, int lane, int wv, 
       else if constexpr (NIN == 2) return w == own.n;  // NOUT == 1: the n = 0 and n = 1 owners read the same two sources
       else return true;                                // NIN == 1: one owner per (m, source pair)
     };
-    constexpr bool kHalves = HBR_K4_TAKE_HALVES && NSRC == 4;
-    // the reads are issued ahead of the MFMAs (all of them, or two sources ahead); each source's fragments are then
-    // claimed in turn, so the waits are lgkmcnt(remaining) rather than full drains (hipcc otherwise sinks every read
-    // next to its MFMA)
+    constexpr bool kHalves = NSRC == 4;  // four sources: two at a time (32 instead of 64 fragment registers)
+    // the reads are issued two sources ahead of their MFMAs; each source's fragments are then claimed in turn, so the
+    // waits are lgkmcnt(remaining) rather than full drains (hipcc otherwise sinks every read next to its MFMA)
 #pragma unroll
     for (int w = 0; w < (kHalves ? 2 : NSRC); ++w) request(w);
     const u32x4 ohw = {ba.onehot[layer], ba.onehot[layer], ba.onehot[layer], ba.onehot[layer]};
@@ -1038,8 +974,8 @@ __device__ __forceinline__ void xch_take(char* xch, int& buf, int lane, int wv, 
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         // the claim above may have moved fragments with v_mov: pad the first MFMA behind it (VALU write -> MFMA read)
-        if (s == 0) PBf16::mfma_acc_lds<(WORDS > 0), (HBR_K4_NOP >= 1)>(fa[w][s], fb[w][s], acc);
-        else PBf16::mfma_acc_lds<(WORDS > 0), (HBR_K4_NOP == 2)>(fa[w][s], fb[w][s], acc);
+        if (s == 0) PBf16::mfma_acc_lds<(WORDS > 0), true>(fa[w][s], fb[w][s], acc);
+        else PBf16::mfma_acc_lds<(WORDS > 0), false>(fa[w][s], fb[w][s], acc);
         constexpr int NM = 2 * NSRC;
         const int i = 2 * w + s;
 #pragma unroll
@@ -1048,52 +984,27 @@ __device__ __forceinline__ void xch_take(char* xch, int& buf, int lane, int wv, 
       // bias gradient of out tile m = sum over points of dZ: one more MFMA per fragment, against an operand that is 1 in
       // row `layer`'s slot of the shared bias tile and 0 elsewhere (8 issue cycles; four v_dot2c per fragment cost ~40)
       if (sums_bias(w)) {
-        PBf16::mfma_acc_lds<(WORDS > 0), (HBR_K4_NOP >= 1)>(onehot, fb[w][0], ba.tile);  // `onehot` is assembled by v_mov
-        PBf16::mfma_acc_lds<(WORDS > 0), (HBR_K4_NOP == 2)>(onehot, fb[w][1], ba.tile);
+        PBf16::mfma_acc_lds<(WORDS > 0), true>(onehot, fb[w][0], ba.tile);  // `onehot` is assembled by v_mov
+        PBf16::mfma_acc_lds<(WORDS > 0), false>(onehot, fb[w][1], ba.tile);
       }
       if constexpr (kHalves) {
         if (w + 2 < NSRC) request(w + 2);
       }
     }
   } else {
+    // f32: fragments already transposed by xch_put, one source at a time (16 + 16 registers in flight)
     const char* base = xch + buf * X::BUF_B + own.src0 * X::SLOT_B + lane * (int)sizeof(typename P::frag);
     (void)ba; (void)layer;
-    typename P::frag fa[NSRC][P::S32], fb[NSRC][P::S32];
-    constexpr bool kAllAtOnce = (P::ELEMS == 8);  // bf16: 16 x 4 VGPRs in flight; f32: per source (16 + 16 VGPRs)
-    if (kAllAtOnce) {
+    typename P::frag fa[P::S32], fb[P::S32];
 #pragma unroll
-      for (int w = 0; w < NSRC; ++w)
+    for (int w = 0; w < NSRC; ++w) {
 #pragma unroll
-        for (int s = 0; s < P::S32; ++s) {
-          fa[w][s] = *(const typename P::frag*)(base + w * X::SLOT_B + (own.n * P::S32 + s) * X::FRAG_B);
-          fb[w][s] = *(const typename P::frag*)(base + w * X::SLOT_B + ((2 + own.m) * P::S32 + s) * X::FRAG_B);
-        }
-      // one opaque statement that "uses" every fragment: without it hipcc sinks each ds_read pair back next to its
-      // MFMA and waits lgkmcnt(0) eight times in a row
-      if constexpr (NSRC == 4) {
-        asm volatile("" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]), "+v"(fa[2][1]),
-                          "+v"(fa[3][0]), "+v"(fa[3][1]));
-        asm volatile("" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[2][0]), "+v"(fb[2][1]),
-                          "+v"(fb[3][0]), "+v"(fb[3][1]));
-      } else {
-        asm volatile("" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fb[0][0]), "+v"(fb[0][1]),
-                          "+v"(fb[1][0]), "+v"(fb[1][1]));
+      for (int s = 0; s < P::S32; ++s) {
+        fa[s] = *(const typename P::frag*)(base + w * X::SLOT_B + (own.n * P::S32 + s) * X::FRAG_B);
+        fb[s] = *(const typename P::frag*)(base + w * X::SLOT_B + ((2 + own.m) * P::S32 + s) * X::FRAG_B);
       }
 #pragma unroll
-      for (int w = 0; w < NSRC; ++w)
-#pragma unroll
-        for (int s = 0; s < P::S32; ++s) P::mfma_acc(fa[w][s], fb[w][s], acc);
-    } else {
-#pragma unroll
-      for (int w = 0; w < NSRC; ++w) {
-#pragma unroll
-        for (int s = 0; s < P::S32; ++s) {
-          fa[0][s] = *(const typename P::frag*)(base + w * X::SLOT_B + (own.n * P::S32 + s) * X::FRAG_B);
-          fb[0][s] = *(const typename P::frag*)(base + w * X::SLOT_B + ((2 + own.m) * P::S32 + s) * X::FRAG_B);
-        }
-#pragma unroll
-        for (int s = 0; s < P::S32; ++s) P::mfma_acc(fa[0][s], fb[0][s], acc);
-      }
+      for (int s = 0; s < P::S32; ++s) P::mfma_acc(fa[s], fb[s], acc);
     }
   }
   buf ^= 1;
@@ -1106,7 +1017,7 @@ template <class P, int NT, int NIN, int NOUT>
 __device__ __forceinline__ void mask_take(f32x16 (&a)[NT], const typename P::frag (&h)[NT * P::S32],
                                           typename P::frag (&out)[NT * P::S32], char* xch, int& buf, int lane, int wv,
                                           f32x16& acc, BiasAcc& ba, int layer, PhaseClock& pc, int ph) {
-  if constexpr (P::ELEMS == 8 && HBR_XCH_TR && HBR_K4_INTERLEAVE) {
+  if constexpr (kXchImage<P>) {
     constexpr int WORDS = NT * P::S32 * 4;
     uint32_t ow[WORDS];
     uint32_t ones = 0x00010001u;
@@ -1297,7 +1208,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
   // ---- flush: every wave parks its registers in the workgroup's slab (plain coalesced stores; mlp_dw_reduce_kernel
   // turns the slabs into parameter gradients)
   asm volatile("s_nop 15" ::: "memory");  // last asm MFMA's D -> first VALU reader
-  if constexpr (P::ELEMS == 8 && HBR_XCH_TR) {  // layer l, out tile own.m: register l of the lower lane half
+  if constexpr (kXchImage<P>) {  // layer l, out tile own.m: register l of the lower lane half
     auto park = [&](int l, int m, int nout) {
       const float v = h ? 0.f : ba.tile[l];
       bsum[db_base(l)] = (m == 0) ? v : 0.f;
