@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("HBR_LIB") or os.path.join(_HERE, "libhbr_hip.so")
 
 ROWS, PLANAR = 0, 1
 F32, BF16 = 0, 1
+IMAGE_READY = 0x100  # hbr_hip.h: OR-ed into hbr_mlp_bwd's precision
 MLP_PARAM_FLOATS = 14227
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float

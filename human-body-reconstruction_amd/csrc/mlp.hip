@@ -1394,6 +1394,10 @@ extern "C" int hbr_mlp_fwd(const void* feat, int layout, int64_t feat_stride, in
 extern "C" int hbr_mlp_bwd(const void* feat, int layout, int64_t feat_stride, int feat_dtype, const float* viewdirs_enc,
                            int64_t N, int64_t group, const float* params, int precision, const float* dout, void* dfeat,
                            float* dfeat_absmax, float* dparams, void* ws, int64_t ws_bytes, void* stream) {
+  // HBR_IMAGE_READY: `ws` still holds the fragment image hbr_mlp_fwd / hbr_mlp_bwd built from THESE params at this
+  // precision (a training step's forward, then its backward): skip the 5 us pack launch
+  const bool image_ready = (precision & HBR_IMAGE_READY) != 0;
+  precision &= ~HBR_IMAGE_READY;
   int rc = check_common(feat, layout, feat_stride, feat_dtype, viewdirs_enc, N, group, params, precision, ws, ws_bytes);
   if (rc) return rc;
   if (!dout || !dparams || ((uintptr_t)dout & 15)) return HBR_EINVAL;
@@ -1404,8 +1408,10 @@ extern "C" int hbr_mlp_bwd(const void* feat, int layout, int64_t feat_stride, in
   DFeatDst dfd{dfeat, feat_stride, nullptr};
   const uint32_t ntiles = (uint32_t)((N + 31) / 32);
   char* img = (char*)ws;
-  if (precision == HBR_BF16) pack<PBf16>(params, img, st);
-  else pack<PF32>(params, img, st);
+  if (!image_ready) {
+    if (precision == HBR_BF16) pack<PBf16>(params, img, st);
+    else pack<PF32>(params, img, st);
+  }
   if (layout == HBR_LAYOUT_PLANAR) {
     if (feat_dtype == HBR_F32) rc = launch_bwd<HBR_LAYOUT_PLANAR, HBR_F32>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams, dfeat_absmax);
     else rc = launch_bwd<HBR_LAYOUT_PLANAR, HBR_BF16>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams, dfeat_absmax);

@@ -12,7 +12,7 @@ from typing import Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, PLANAR, ROWS, HbrError, check, lib, require_gpu
+from ._lib import BF16, F32, IMAGE_READY, PLANAR, ROWS, HbrError, check, lib, require_gpu
 
 _ws_cache = {}
 _MAX_SCATTER_WS = 8 << 30  # largest K2 workspace allocated for the reproducible (slab) flush
@@ -195,8 +195,11 @@ def mlp_fwd(feat: torch.Tensor, layout: int, viewdirs_enc: torch.Tensor, group: 
 
 
 def mlp_bwd(feat: torch.Tensor, layout: int, viewdirs_enc: torch.Tensor, group: int, params: torch.Tensor, precision: int,
-            dout: torch.Tensor, dparams: torch.Tensor, need_dfeat: bool = True, absmax_out: Optional[torch.Tensor] = None):
-    """absmax_out: optional [16] fp32 device tensor that receives max |d feat| per level (hash_encode_bwd's dy_absmax)."""
+            dout: torch.Tensor, dparams: torch.Tensor, need_dfeat: bool = True, absmax_out: Optional[torch.Tensor] = None,
+            image_ready: bool = False):
+    """absmax_out: optional [16] fp32 device tensor that receives max |d feat| per level (hash_encode_bwd's dy_absmax).
+    image_ready: the last MLP call on this stream was `mlp_fwd` / `mlp_bwd` with the SAME params and precision (the
+    workspace still holds their fragment image) - skips the repack."""
     N, stride, dtype = _feat_desc(feat, layout)
     # d feat takes feat's layout INCLUDING its row stride (the kernel addresses both with feat_stride): a strided rows
     # view such as y[:, :32] of an [N,36] buffer gets a gradient buffer with the same 36-element pitch
@@ -208,7 +211,7 @@ def mlp_bwd(feat: torch.Tensor, layout: int, viewdirs_enc: torch.Tensor, group: 
             absmax_out.zero_()
         return dfeat
     check(lib().hbr_mlp_bwd(feat.data_ptr(), layout, stride, dtype, viewdirs_enc.data_ptr(), N, group, params.data_ptr(),
-                            precision, dout.data_ptr(), _ptr(dfeat), _ptr(absmax_out), dparams.data_ptr(), ws.data_ptr(), ws.numel(),
+                            precision | (IMAGE_READY if image_ready else 0), dout.data_ptr(), _ptr(dfeat), _ptr(absmax_out), dparams.data_ptr(), ws.data_ptr(), ws.numel(),
                             _stream()), "hbr_mlp_bwd")
     return dfeat
 

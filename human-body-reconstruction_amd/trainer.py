@@ -125,8 +125,9 @@ class HashNeRFTrainer:
         self.grad.zero_()
         # K4 also reports max |d feat| per level: K2's fixed-point scale, without K2 re-reading the buffer for it
         amax = self._amax if g.L == 16 else None
+        # (image_ready: the workspace still holds the weight fragments this step's mlp_fwd packed from self.flat)
         dfeat = self._timed("mlp_bwd", lambda: ops.mlp_bwd(feat, PLANAR, pe, S, self.flat, self.precision, d_out, self.g_mlp,
-                                                           absmax_out=amax))
+                                                           absmax_out=amax, image_ready=True))
         if self.split_scatter and g.L >= 2:
             # The step's one all-reduce, issued in three pieces that partition the flat gradient buffer: the MLP block
             # (final after K4), then the upper half of the levels while the lower half's scatter is still running.

@@ -42,6 +42,10 @@ enum {
 };
 
 enum { HBR_F32 = 0, HBR_BF16 = 1 };
+/* OR-ed into hbr_mlp_bwd's `precision`: the workspace still holds the weight-fragment image that the previous
+ * hbr_mlp_fwd / hbr_mlp_bwd call built from the same `params` at the same precision (forward then backward of one
+ * training step), so the backward need not pack it again. */
+enum { HBR_IMAGE_READY = 0x100 };
 
 int hbr_version(void);
 const char* hbr_strerror(int code);

@@ -470,3 +470,32 @@ def test_mlp_instantiations_agree_bit_for_bit(ops, precision):
         assert torch.equal(df, ref[2]), ("dfeat", key)
         if amax is not None:
             assert torch.equal(amax, ref[3]), ("absmax", key)
+
+
+@pytest.mark.parametrize("precision", [1, 0])
+def test_mlp_bwd_reuses_the_forward_image(ops, precision):
+    """HBR_IMAGE_READY: the backward right after a forward with the same parameters skips the repack and returns the
+    same bits; with the flag wrongly set after OTHER parameters were packed it would not - which is what makes the
+    check meaningful."""
+    from hbr_amd._lib import PLANAR
+    g = torch.Generator().manual_seed(5)
+    N = 1000
+    feat = (torch.randn((16, N, 2), generator=g) * 0.3).to(DEV)
+    pe = ops.dir_encode(torch.nn.functional.normalize(torch.randn((N, 3), generator=g), dim=1).to(DEV), 4)
+    dout = torch.randn((N, 4), generator=g).to(DEV)
+    P = torch.cat([v.reshape(-1) for v in ref_cpu.mlp_init(2).values()]).to(DEV)
+    P2 = torch.cat([v.reshape(-1) for v in ref_cpu.mlp_init(3).values()]).to(DEV)
+
+    def bwd(ready):
+        dP = torch.zeros_like(P)
+        df = ops.mlp_bwd(feat, PLANAR, pe, 1, P, precision, dout, dP, image_ready=ready)
+        return df.clone(), dP
+
+    ops.mlp_fwd(feat, PLANAR, pe, 1, P, precision)
+    ref = bwd(False)
+    ops.mlp_fwd(feat, PLANAR, pe, 1, P, precision)
+    got = bwd(True)
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    ops.mlp_fwd(feat, PLANAR, pe, 1, P2, precision)   # a different image in the workspace
+    stale = bwd(True)
+    assert not torch.equal(stale[1], ref[1])
