@@ -902,11 +902,6 @@ __device__ __forceinline__ void xch_put(char* xch, int buf, int lane, int wv, co
   }
 }
 
-// ---- second half: meet the workgroup, then accumulate MY dW^T tile of the layer over the source waves' fragments
-// `epi(k)`, k = 0..WORDS-1: the caller's VALU epilogue of the dense it has just issued (re-pack + ReLU mask of one
-// output word), cut into words.  The bf16 path slots WORDS / (number of owner MFMAs) of them behind each owner MFMA:
-// the two are independent, so the epilogue runs in the shadow of the 32-cycle MFMAs instead of in front of them (one
-// wave per SIMD: nothing else would overlap them).  The statements involved are volatile asm, which pins the order.
 // bf16 bias gradients: ONE accumulator tile for all six layers.  Layer l's sums (over the points, of the out tile this
 // wave owns) live in row acc_row(l, 0) of it, i.e. in register l of the lanes 0..31 (column = out feature).
 struct BiasAcc {
@@ -923,49 +918,56 @@ struct BiasAcc {
   }
 };
 
-struct NoEpi {
-  __device__ __forceinline__ void operator()(int) const {}
-};
-template <class P, int NIN, int NOUT, int WORDS = 0, class Epi = NoEpi>
-__device__ __forceinline__ void xch_take(char* xch, int& buf, int lane, int wv, f32x16& acc, BiasAcc& ba, int layer, PhaseClock& pc,
-                                         int ph, Epi epi = Epi()) {
-  using X = Xch<P>;
+// ---- second half of a layer's exchange
+// The owner side, bf16.  begin(): meet the workgroup, then request the first two source waves'
+// fragments.  run(): accumulate MY dW^T tile over all source waves (and, by one more MFMA per fragment against a
+// one-hot operand, the bias gradients), with the caller's epilogue words slotted behind the MFMAs.  Whatever the
+// caller issues between the two (the next dense's MFMAs) runs while the transposing reads are in flight.
+template <int NIN, int NOUT>
+struct Owner {
+  using X = Xch<PBf16>;
   using O = Own<NIN, NOUT>;
-  constexpr int NSRC = O::NSRC;
-  static_assert(kXchImage<P> || WORDS == 0, "only the bf16 path takes an epilogue");
-  pc.mark(ph);      // put + dense (+ the f32 epilogue)
-  __syncthreads();
-  pc.mark(ph + 1);  // waiting for the slowest wave
-  const O own(wv);
-  if constexpr (kXchImage<P>) {
+  static constexpr int NSRC = O::NSRC;
+  static constexpr bool kHalves = NSRC == 4;  // four sources: two at a time (32 instead of 64 fragment registers)
+  const char *a0, *a1, *b0, *b1;
+  bf16x8 fa[NSRC][2], fb[NSRC][2];
+  int n, m;
+
+  __device__ __forceinline__ void request(int w) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {  // points 16s + 8h + j of source wave src0 + w
+      const int o = w * X::SLOT_B + s * 16 * 256;
+      fa[w][s] = lds_tr_frag(a0 + o, a1 + o);
+      fb[w][s] = lds_tr_frag(b0 + o, b1 + o);
+    }
+  }
+  __device__ __forceinline__ void begin(const char* xch, int buf, int lane, int wv, PhaseClock& pc, int ph) {
+    pc.mark(ph);      // put (+ dense when it is issued first)
+    __syncthreads();
+    pc.mark(ph + 1);  // waiting for the slowest wave
+    const O own(wv);
+    n = own.n; m = own.m;
     // lane (group g of its half, q, p) supplies row q, columns 4p..4p+3 of its group's 4-point x 16-feature block
     const int h = lane >> 5, g = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
     const char* src = xch + buf * X::BUF_B + own.src0 * X::SLOT_B + 8 * (p & 1);
-    const char* a0 = src + xch_off(8 * h + q, 4 * own.n + 2 * g + (p >> 1));
-    const char* a1 = src + xch_off(8 * h + 4 + q, 4 * own.n + 2 * g + (p >> 1));
-    const char* b0 = src + xch_off(8 * h + q, 8 + 4 * own.m + 2 * g + (p >> 1));
-    const char* b1 = src + xch_off(8 * h + 4 + q, 8 + 4 * own.m + 2 * g + (p >> 1));
-    bf16x8 fa[NSRC][2], fb[NSRC][2];
-    auto request = [&](int w) {
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {  // points 16s + 8h + j of source wave src0 + w
-        const int o = w * X::SLOT_B + s * 16 * 256;
-        fa[w][s] = lds_tr_frag(a0 + o, a1 + o);
-        fb[w][s] = lds_tr_frag(b0 + o, b1 + o);
-      }
-    };
-    // which sources' dZ this wave sums into the bias gradient: every (out tile, source) pair is summed by exactly one
-    // of the waves that read it - the owners of (n, m) for n = 0, 1 split the source list by n
-    auto sums_bias = [&](int w) {
-      if constexpr (O::tiles == 4) return (w < 2) == (own.n == 0);
-      else if constexpr (NIN == 2) return w == own.n;  // NOUT == 1: the n = 0 and n = 1 owners read the same two sources
-      else return true;                                // NIN == 1: one owner per (m, source pair)
-    };
-    constexpr bool kHalves = NSRC == 4;  // four sources: two at a time (32 instead of 64 fragment registers)
+    a0 = src + xch_off(8 * h + q, 4 * n + 2 * g + (p >> 1));
+    a1 = src + xch_off(8 * h + 4 + q, 4 * n + 2 * g + (p >> 1));
+    b0 = src + xch_off(8 * h + q, 8 + 4 * m + 2 * g + (p >> 1));
+    b1 = src + xch_off(8 * h + 4 + q, 8 + 4 * m + 2 * g + (p >> 1));
     // the reads are issued two sources ahead of their MFMAs; each source's fragments are then claimed in turn, so the
     // waits are lgkmcnt(remaining) rather than full drains (hipcc otherwise sinks every read next to its MFMA)
 #pragma unroll
     for (int w = 0; w < (kHalves ? 2 : NSRC); ++w) request(w);
+  }
+  // which sources' dZ this wave sums into the bias gradient: every (out tile, source) pair is summed by exactly one
+  // of the waves that read it - the owners of (n, m) for n = 0, 1 split the source list by n
+  __device__ __forceinline__ bool sums_bias(int w) const {
+    if constexpr (O::tiles == 4) return (w < 2) == (n == 0);
+    else if constexpr (NIN == 2) return w == n;  // NOUT == 1: the n = 0 and n = 1 owners read the same two sources
+    else return true;                            // NIN == 1: one owner per (m, source pair)
+  }
+  template <int WORDS, class Epi>
+  __device__ __forceinline__ void run(int& buf, f32x16& acc, BiasAcc& ba, int layer, PhaseClock& pc, int ph, Epi epi) {
     const u32x4 ohw = {ba.onehot[layer], ba.onehot[layer], ba.onehot[layer], ba.onehot[layer]};
     const bf16x8 onehot = __builtin_bit_cast(bf16x8, ohw);
 #pragma unroll
@@ -991,13 +993,36 @@ __device__ __forceinline__ void xch_take(char* xch, int& buf, int lane, int wv, 
         if (w + 2 < NSRC) request(w + 2);
       }
     }
+    buf ^= 1;
+    pc.mark(ph + 2);  // (dense +) owner MFMAs with the epilogue in their shadow
+  }
+};
+
+struct NoEpi {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+// `epi(k)`, k = 0..WORDS-1 (bf16 only): the caller's VALU epilogue of the dense it has just issued, cut into words
+template <class P, int NIN, int NOUT, int WORDS = 0, class Epi = NoEpi>
+__device__ __forceinline__ void xch_take(char* xch, int& buf, int lane, int wv, f32x16& acc, BiasAcc& ba, int layer, PhaseClock& pc,
+                                         int ph, Epi epi = Epi()) {
+  static_assert(kXchImage<P> || WORDS == 0, "only the bf16 path takes an epilogue");
+  if constexpr (kXchImage<P>) {
+    Owner<NIN, NOUT> ow;
+    ow.begin(xch, buf, lane, wv, pc, ph);
+    ow.template run<WORDS>(buf, acc, ba, layer, pc, ph, epi);
   } else {
+    using X = Xch<P>;
+    using O = Own<NIN, NOUT>;
+    pc.mark(ph);
+    __syncthreads();
+    pc.mark(ph + 1);
+    const O own(wv);
     // f32: fragments already transposed by xch_put, one source at a time (16 + 16 registers in flight)
     const char* base = xch + buf * X::BUF_B + own.src0 * X::SLOT_B + lane * (int)sizeof(typename P::frag);
     (void)ba; (void)layer;
     typename P::frag fa[P::S32], fb[P::S32];
 #pragma unroll
-    for (int w = 0; w < NSRC; ++w) {
+    for (int w = 0; w < O::NSRC; ++w) {
 #pragma unroll
       for (int s = 0; s < P::S32; ++s) {
         fa[s] = *(const typename P::frag*)(base + w * X::SLOT_B + (own.n * P::S32 + s) * X::FRAG_B);
@@ -1006,23 +1031,48 @@ __device__ __forceinline__ void xch_take(char* xch, int& buf, int lane, int wv, 
 #pragma unroll
       for (int s = 0; s < P::S32; ++s) P::mfma_acc(fa[s], fb[s], acc);
     }
+    buf ^= 1;
+    pc.mark(ph + 2);
   }
-  buf ^= 1;
-  pc.mark(ph + 2);  // owner reads + MFMAs (+ the bf16 epilogue in their shadow)
 }
 
-// dZ = mask(dX) of the dense just issued (mask_frags), and the owner half of the PREVIOUS layer's exchange (xch_take).
-// bf16: word by word behind the owner MFMAs; f32: one after the other.
-template <class P, int NT, int NIN, int NOUT>
-__device__ __forceinline__ void mask_take(f32x16 (&a)[NT], const typename P::frag (&h)[NT * P::S32],
-                                          typename P::frag (&out)[NT * P::S32], char* xch, int& buf, int lane, int wv,
-                                          f32x16& acc, BiasAcc& ba, int layer, PhaseClock& pc, int ph) {
+// One backward layer step after the exchange writes (xch_put): the NEXT layer's dense `a = W^T dz`, its ReLU mask
+// (-> `out`, the next dZ) and the owner half of THIS layer's exchange.
+// bf16 order: barrier, request the owners' transposing reads, THEN the dense MFMAs - on weight fragments the caller
+// requested before the exchange writes (`wq`; LDS operations complete in order, so they land first) - and then the
+// owner MFMAs with the mask epilogue word by word in their shadow.  The dense covers the latency of the transposing
+// reads and no longer waits for weight reads queued behind the 8-16 exchange writes (382.6 vs 391.4 us with the dense
+// in front of the barrier).   f32: dense, mask, take.
+constexpr int kMaxDenseFrags = 8;
+template <class P, int NOUT, int NK>
+__device__ __forceinline__ void dense_request(const char* img, int fbase, int lofs, typename P::frag (&wq)[kMaxDenseFrags]) {
+  if constexpr (kXchImage<P>) {
+    static_assert(NOUT * NK <= kMaxDenseFrags, "weight fragments of one backward dense");
+#pragma unroll
+    for (int i = 0; i < NOUT * NK; ++i) wq[i] = ldw<P>(img, fbase + i, lofs);
+  }
+}
+template <class P, int NT, int NK, int NIN, int NOUT>
+__device__ __forceinline__ void dense_mask_take(const char* img, int fbase, int lofs, const typename P::frag (&wq)[kMaxDenseFrags],
+                                                const typename P::frag (&dz)[NK], const typename P::frag (&h)[NT * P::S32],
+                                                typename P::frag (&out)[NT * P::S32], char* xch, int& buf, int lane, int wv,
+                                                f32x16& acc, BiasAcc& ba, int layer, PhaseClock& pc, int ph) {
+  f32x16 a[NT];
   if constexpr (kXchImage<P>) {
     constexpr int WORDS = NT * P::S32 * 4;
     uint32_t ow[WORDS];
     uint32_t ones = 0x00010001u;
     asm volatile("" : "+v"(ones));
-    xch_take<P, NIN, NOUT, WORDS>(xch, buf, lane, wv, acc, ba, layer, pc, ph, [&](int k) {
+    Owner<NIN, NOUT> own;
+    own.begin(xch, buf, lane, wv, pc, ph);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) a[t][q] = 0.f;
+#pragma unroll
+      for (int k = 0; k < NK; ++k) a[t] = P::mfma(wq[t * NK + k], dz[k], a[t]);
+    }
+    own.template run<WORDS>(buf, acc, ba, layer, pc, ph, [&](int k) {
       const int f = k >> 2, t = f / P::S32, s = f % P::S32, j = k & 3;
       const uint32_t g = pack_bf16x2(a[t][8 * s + 2 * j], a[t][8 * s + 2 * j + 1]);
       ow[k] = pk_keep_where_nonzero_ordered(g, __builtin_bit_cast(u32x4, h[f])[j], ones);
@@ -1032,6 +1082,7 @@ __device__ __forceinline__ void mask_take(f32x16 (&a)[NT], const typename P::fra
       out[f] = PBf16::from_words(ow[4 * f], ow[4 * f + 1], ow[4 * f + 2], ow[4 * f + 3]);
     }
   } else {
+    dense<P, NT, NK, 0>(img, fbase, nullptr, lane, lofs, dz, a);
     mask_frags<P, NT>(a, h, out);
     xch_take<P, NIN, NOUT>(xch, buf, lane, wv, acc, ba, layer, pc, ph);
   }
@@ -1108,22 +1159,17 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
       for (int s = 0; s < P::S8; ++s) dz3[s] = P::from_acc(a, s);
     }
     pc.mark(1);  // dZ of the output layer (expf)
-    xch_put<P, 2, 1, 2 * P::S32, P::S8>(xch, buf, lane, wv, sv.c2, dz3, bsum + db_base(C3));  // take: after the next layer's dense
+    typename P::frag wq[kMaxDenseFrags];  // the next dense's weight fragments, requested ahead of the exchange writes
+    dense_request<P, 2, P::S8>(img, T::b_base(C3), lofs, wq);
+    xch_put<P, 2, 1, 2 * P::S32, P::S8>(xch, buf, lane, wv, sv.c2, dz3, bsum + db_base(C3));
     // ---- C2
     typename P::frag dzc2[2 * P::S32];
-    {
-      f32x16 a[2];
-      dense<P, 2, P::S8, 0>(img, T::b_base(C3), nullptr, lane, lofs, dz3, a);
-      mask_take<P, 2, 2, 1>(a, sv.c2, dzc2, xch, buf, lane, wv, acc[C3], ba, C3, pc, 2);
-    }
-    xch_put<P, 2, 2, 2 * P::S32, 2 * P::S32>(xch, buf, lane, wv, sv.c1, dzc2, bsum + db_base(C2));  // take: after the next layer's dense
+    dense_mask_take<P, 2, P::S8, 2, 1>(img, T::b_base(C3), lofs, wq, dz3, sv.c2, dzc2, xch, buf, lane, wv, acc[C3], ba, C3, pc, 2);
+    dense_request<P, 2, 2 * P::S32>(img, T::b_base(C2), lofs, wq);
+    xch_put<P, 2, 2, 2 * P::S32, 2 * P::S32>(xch, buf, lane, wv, sv.c1, dzc2, bsum + db_base(C2));
     // ---- C1
     typename P::frag dzc1[2 * P::S32];
-    {
-      f32x16 a[2];
-      dense<P, 2, 2 * P::S32, 0>(img, T::b_base(C2), nullptr, lane, lofs, dzc2, a);
-      mask_take<P, 2, 2, 2>(a, sv.c1, dzc1, xch, buf, lane, wv, acc[C2], ba, C2, pc, 5);
-    }
+    dense_mask_take<P, 2, 2 * P::S32, 2, 2>(img, T::b_base(C2), lofs, wq, dzc2, sv.c1, dzc1, xch, buf, lane, wv, acc[C2], ba, C2, pc, 5);
     xch_put<P, 2, 2, P::S32 + P::S8, 2 * P::S32>(xch, buf, lane, wv, sv.cin, dzc1, bsum + db_base(C1));  // take: after the next layer's dense
     // ---- L3: ds rows 1..15 = d cin slots 1..15 ; row 0 = d sigma * lrelu'(s0)
     typename P::frag dz_s[P::S16];
@@ -1135,22 +1181,16 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
       for (int s = 0; s < P::S16; ++s) dz_s[s] = P::from_acc(a[0], s);
     }
     xch_take<P, 2, 2>(xch, buf, lane, wv, acc[C1], ba, C1, pc, 8);
-    xch_put<P, 2, 1, 2 * P::S32, P::S16>(xch, buf, lane, wv, sv.h2, dz_s, bsum + db_base(L3));  // take: after the next layer's dense
+    dense_request<P, 2, P::S16>(img, T::b_base(L3), lofs, wq);
+    xch_put<P, 2, 1, 2 * P::S32, P::S16>(xch, buf, lane, wv, sv.h2, dz_s, bsum + db_base(L3));
     // ---- L2
     typename P::frag dz2[2 * P::S32];
-    {
-      f32x16 a[2];
-      dense<P, 2, P::S16, 0>(img, T::b_base(L3), nullptr, lane, lofs, dz_s, a);
-      mask_take<P, 2, 2, 1>(a, sv.h2, dz2, xch, buf, lane, wv, acc[L3], ba, L3, pc, 11);
-    }
-    xch_put<P, 2, 2, 2 * P::S32, 2 * P::S32>(xch, buf, lane, wv, sv.h1, dz2, bsum + db_base(L2));  // take: after the next layer's dense
+    dense_mask_take<P, 2, P::S16, 2, 1>(img, T::b_base(L3), lofs, wq, dz_s, sv.h2, dz2, xch, buf, lane, wv, acc[L3], ba, L3, pc, 11);
+    dense_request<P, 2, 2 * P::S32>(img, T::b_base(L2), lofs, wq);
+    xch_put<P, 2, 2, 2 * P::S32, 2 * P::S32>(xch, buf, lane, wv, sv.h1, dz2, bsum + db_base(L2));
     // ---- L1
     typename P::frag dz1[2 * P::S32];
-    {
-      f32x16 a[2];
-      dense<P, 2, 2 * P::S32, 0>(img, T::b_base(L2), nullptr, lane, lofs, dz2, a);
-      mask_take<P, 2, 2, 2>(a, sv.h1, dz1, xch, buf, lane, wv, acc[L2], ba, L2, pc, 14);
-    }
+    dense_mask_take<P, 2, 2 * P::S32, 2, 2>(img, T::b_base(L2), lofs, wq, dz2, sv.h1, dz1, xch, buf, lane, wv, acc[L2], ba, L2, pc, 14);
     xch_put<P, 1, 2, P::S32, 2 * P::S32>(xch, buf, lane, wv, sv.x0, dz1, bsum + db_base(L1));  // take: after the next layer's dense
     // ---- d feat
     if (dfd.p) {
