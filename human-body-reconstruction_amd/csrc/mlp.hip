@@ -397,6 +397,9 @@ struct PhaseClock {
     if (on) k4_prof[i] += (unsigned long long)(t1 - t0);
     t0 = clock64();
   }
+  __device__ __forceinline__ void mark_fine(int i) {
+    if (HBR_K4_PROF == 3) { const int keep = HBR_K4_PROF; (void)keep; mark(i); }
+  }
   // the same after the values in `v` exist (an MFMA result, a re-packed fragment): pins the producers before the stamp
   template <class V>
   __device__ __forceinline__ void mark_after(int i, V& v) {
@@ -410,6 +413,7 @@ struct PhaseClock {
   __device__ __forceinline__ void start() {}
   __device__ __forceinline__ void finish() {}
   __device__ __forceinline__ void mark(int) {}
+  __device__ __forceinline__ void mark_fine(int) {}
   template <class V>
   __device__ __forceinline__ void mark_after(int, V&) {}
 };
@@ -973,6 +977,7 @@ struct Owner {
 #pragma unroll
     for (int w = 0; w < NSRC; ++w) {
       asm volatile("" : "+v"(fa[w][0]), "+v"(fa[w][1]), "+v"(fb[w][0]), "+v"(fb[w][1]));
+      if (w == 0) pc.mark_fine(32 + 5 * layer + 4);  // (+ dense and) the first source's fragments have arrived
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         // the claim above may have moved fragments with v_mov: pad the first MFMA behind it (VALU write -> MFMA read)
@@ -992,6 +997,7 @@ struct Owner {
       if constexpr (kHalves) {
         if (w + 2 < NSRC) request(w + 2);
       }
+      pc.mark_fine(32 + 5 * layer + w);  // source w: two owner MFMAs + its epilogue words (+ two bias MFMAs)
     }
     buf ^= 1;
     pc.mark(ph + 2);  // (dense +) owner MFMAs with the epilogue in their shadow

@@ -37,6 +37,9 @@ names += ["fwd: inputs arrive + unpack"]
 for l in ("L1", "L2", "L3", "C1", "C2"):
     names += [f"fwd {l}: dense", f"fwd {l}: epilogue"]
 names += ["fwd C3: dense"]
+if buf[36] or buf[32]:  # -DHBR_K4_PROF=3: inside the owner phases (layer order L1 L2 L3 C1 C2 C3 = 0..5)
+    for li, l in enumerate(("L1", "L2", "L3", "C1", "C2", "C3")):
+        names += [f"  own {l}: source {w}" for w in range(4)] + [f"  own {l}: dense + first fragments arrive"]
 tot = sum(buf[i] for i in range(len(names)))
 print(f"{os.environ.get('HBR_LIB', 'default')}: {e0.elapsed_time(e1) / CALLS:.4f} ms per call (instrumented); {tot / tiles:.0f} cycles per tile in marked phases")
 if tot == 0:
