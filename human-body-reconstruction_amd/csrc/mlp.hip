@@ -622,6 +622,92 @@ __device__ __forceinline__ void forward_tile(const char* img, const float* bias,
   forward_layer<P, BSTEP, C3>(img, bias, lane, lofs, ti.peA, ti.peB, ti.peC, sv, pc);
 }
 
+// The backward kernel's forward recompute (bf16, one wave per SIMD): every layer's weight fragments - its bias step
+// included - are requested one layer AHEAD, in front of the previous layer's MFMAs, and a scheduling fence that LDS
+// operations may not cross keeps hipcc from sinking the reads back next to their MFMAs (it otherwise emits
+// ds_read -> s_waitcnt -> v_mfma per k-step, exposing the LDS latency several times per layer): 12.65 k -> 12.2 k cycles
+// per tile, of which the chip takes a part back as clock (2.13 -> 2.08 GHz): 391.7 -> 382.6 us.
+constexpr int kFwdFrags = 10;  // 2 output tiles x (4 k-steps + the bias step)
+template <int LAYER>
+struct FwdShape {
+  static constexpr int NOUT = (LAYER == L3 || LAYER == C3) ? 1 : 2;
+  static constexpr int NK = Tab<PBf16>::f_wsteps(LAYER);
+  static constexpr int FRAGS = NOUT * (NK + 1);
+};
+template <int LAYER>
+__device__ __forceinline__ void fwd_request(const char* img, int lofs, bf16x8 (&w)[kFwdFrags]) {
+  static_assert(FwdShape<LAYER>::FRAGS <= kFwdFrags, "fragments of one forward layer");
+#pragma unroll
+  for (int i = 0; i < FwdShape<LAYER>::FRAGS; ++i) w[i] = ldw<PBf16>(img, Tab<PBf16>::f_base(LAYER) + i, lofs);
+  __builtin_amdgcn_sched_barrier(0);  // nothing is scheduled across: the requests stay in front of the previous layer
+}
+template <int LAYER>
+__device__ __forceinline__ void fwd_dense(const bf16x8 (&w)[kFwdFrags], const bf16x8 (&x)[FwdShape<LAYER>::NK], bf16x8 ones,
+                                          f32x16 (&acc)[FwdShape<LAYER>::NOUT]) {
+  constexpr int NK = FwdShape<LAYER>::NK;
+#pragma unroll
+  for (int m = 0; m < FwdShape<LAYER>::NOUT; ++m) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[m][q] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) acc[m] = PBf16::mfma(w[m * (NK + 1) + k], x[k], acc[m]);
+    acc[m] = PBf16::mfma(w[m * (NK + 1) + NK], ones, acc[m]);
+  }
+}
+template <int DT>
+__device__ __forceinline__ void forward_tile_prefetched(const char* img, const TileIn& ti, int lane, Saved<PBf16>& sv, PhaseClock& pc) {
+  using P = PBf16;
+  const int lofs = opaque_lane_offset<P>(lane);
+  const int h = lane >> 5;
+  const bf16x8 ones = P::from_words(h ? 0u : 0x3f803f80u, h ? 0u : 0x00003f80u, 0u, 0u);  // dense(): the bias step's activations
+  bf16x8 wa[kFwdFrags], wb[kFwdFrags];
+  fwd_request<L1>(img, lofs, wa);
+  feat_frags<P, DT>(ti, sv.x0);
+  pc.mark_after(20, sv.x0[P::S32 - 1]);
+  fwd_request<L2>(img, lofs, wb);
+  {
+    f32x16 a[2];
+    fwd_dense<L1>(wa, sv.x0, ones, a);
+    pc.mark_after(21, a[1]);
+    relu_frags<P, 2>(a, sv.h1);
+  }
+  fwd_request<L3>(img, lofs, wa);
+  {
+    f32x16 a[2];
+    fwd_dense<L2>(wb, sv.h1, ones, a);
+    pc.mark_after(23, a[1]);
+    relu_frags<P, 2>(a, sv.h2);
+  }
+  fwd_request<C1>(img, lofs, wb);
+  {
+    f32x16 a[1];
+    fwd_dense<L3>(wa, sv.h2, ones, a);
+    pc.mark_after(25, a[0]);
+    sv.s0 = a[0][0];
+    P::cin(a[0], ti.peA, ti.peB, ti.peC, sv.cin);
+  }
+  fwd_request<C2>(img, lofs, wa);
+  {
+    f32x16 a[2];
+    fwd_dense<C1>(wb, sv.cin, ones, a);
+    pc.mark_after(27, a[1]);
+    relu_frags<P, 2>(a, sv.c1);
+  }
+  fwd_request<C3>(img, lofs, wb);
+  {
+    f32x16 a[2];
+    fwd_dense<C2>(wa, sv.c1, ones, a);
+    pc.mark_after(29, a[1]);
+    relu_frags<P, 2>(a, sv.c2);
+  }
+  {
+    f32x16 a[1];
+    fwd_dense<C3>(wb, sv.c2, ones, a);
+    pc.mark_after(31, a[0]);
+    sv.raw[0] = a[0][0]; sv.raw[1] = a[0][1]; sv.raw[2] = a[0][2];
+  }
+}
+
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }          // test_hash.py:38,67
 __device__ __forceinline__ float lrelu(float x) { return x > 0.f ? x : 0.01f * x; }          // test_hash.py:39,62
 
@@ -1148,7 +1234,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
     load_tile_in<LAYOUT, DT, true>(fs, ps, dout, ahead, ahead.n < fs.N, h, nxt);
     pc.mark(0);  // next tile's loads issued
     Saved<P> sv;
-    forward_tile<P, DT, true>(img, bias, cur, lane, sv, pc);
+    if constexpr (P::ELEMS == 8) forward_tile_prefetched<DT>(img, cur, lane, sv, pc);
+    else forward_tile<P, DT, true>(img, bias, cur, lane, sv, pc);
     const int lofs = opaque_lane_offset<P>(lane);
     const float4 dO = cur.dO;  // zero on invalid lanes => every dZ of such a point is zero
 
