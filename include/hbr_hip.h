@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HBR_VERSION 200 /* 0.2.0 */
+#define HBR_VERSION 201 /* 0.2.1: HBR_IMAGE_READY */
 
 enum {
   HBR_OK = 0,
