@@ -719,7 +719,10 @@ __device__ __forceinline__ void stage_image(char* dst, const char* src, int byte
 // ------------------------------------------------------------------------------------------------
 // forward kernel
 // ------------------------------------------------------------------------------------------------
-constexpr int kFwdWaves = 4;
+// Waves per workgroup = waves sharing one staged weight image.  With 4 (round 1) the 46 KiB image let three workgroups
+// = 3 waves per SIMD onto a CU; 16 waves around one image give the 4 per SIMD the 117-126 VGPRs allow:
+// 0.087-0.089 ms (4), 0.078-0.080 (8), 0.075-0.078 (16) for pack + kernel at 2 M points.
+constexpr int kFwdWaves = 16;
 
 template <class P, int LAYOUT, int DT>
 __global__ __launch_bounds__(kFwdWaves * 64) void mlp_fwd_kernel(const char* __restrict__ gimg, FeatSrc fs, PeSrc ps,
@@ -1510,7 +1513,7 @@ extern "C" int hbr_mlp_fwd(const void* feat, int layout, int64_t feat_stride, in
   PeSrc ps{viewdirs_enc, (uint32_t)group};
   const uint32_t ntiles = (uint32_t)((N + 31) / 32);
   uint32_t blocks = (ntiles + kFwdWaves - 1) / kFwdWaves;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 4096 / kFwdWaves) blocks = 4096 / kFwdWaves;
   char* img = (char*)ws;
   if (precision == HBR_BF16) {
     pack<PBf16>(params, img, st);
