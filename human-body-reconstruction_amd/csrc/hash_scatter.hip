@@ -127,7 +127,12 @@ __device__ __forceinline__ LevelPlan level_plan(const Meta* __restrict__ m, cons
 // lane i of wave w of the hashed kernel / sample w of lane i's segment in the dense kernel - fully coalesced 12-byte
 // reads in both.  Consecutive samples of a ray share their cell at the coarse levels, and 64 lanes adding to one LDS
 // address serialise; with lanes 16 samples apart they do not (level 0 cost 3.2x a fine level with the natural map).
-__global__ __launch_bounds__(1024) void normalise_kernel(PointSrc ps, uint32_t N, HashGeom g, float* __restrict__ out) {
+// The same launch takes the bounding box of its 1024 coordinates: part [block][7] = lo xyz, hi xyz, finite (round 2
+// first took the boxes of the rays' end points in a launch of its own; per point they are exact, cost nothing next to
+// the 12 bytes the thread stores, and that launch is gone).
+__global__ __launch_bounds__(1024) void normalise_kernel(PointSrc ps, uint32_t N, HashGeom g, float* __restrict__ out,
+                                                         float* __restrict__ part) {
+  __shared__ float red[16][7];
   const uint32_t base = blockIdx.x * 1024u;
   const uint32_t n_raw = base + (threadIdx.x & 63u) * 16u + (threadIdx.x >> 6);
   const uint32_t n = min(n_raw, N - 1);
@@ -136,52 +141,8 @@ __global__ __launch_bounds__(1024) void normalise_kernel(PointSrc ps, uint32_t N
   normalise(g, px, py, pz, nx, ny, nz);
   float* q = out + (size_t)(base + threadIdx.x) * 3;
   q[0] = nx; q[1] = ny; q[2] = nz;
-}
-
-// Bounding box of the normalised coordinates, one partial box per block: part [block][7] = lo xyz, hi xyz, finite.
-// Ray mode: p = o + d*t and (p - mu)/sigma are chains of correctly rounded monotonic operations in t, so a ray's
-// coordinates are bounded, exactly, by their values at the smallest and largest t - two evaluations per ray instead
-// of one per point.  Point mode: items are the N points themselves.
-__global__ __launch_bounds__(1024) void bounds_kernel(PointSrc ps, uint32_t items, HashGeom g, float* __restrict__ part) {
-  __shared__ float red[16][7];
-  __shared__ float trange[3];
-  const float inf = __uint_as_float(0x7f800000u);
-  if (!ps.x) {  // min / max of the shared t[S]
-    float lo = inf, hi = -inf, ok = 1.f;
-    for (uint32_t s = threadIdx.x; s < ps.S; s += 1024) {
-      const float tt = ps.t[s];
-      lo = fminf(lo, tt); hi = fmaxf(hi, tt);
-      if (!isfinite(tt)) ok = 0.f;  // fminf/fmaxf skip a NaN: the box would not cover that sample
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); ok = fminf(ok, __shfl_xor(ok, o)); }
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = lo; red[threadIdx.x >> 6][1] = hi; red[threadIdx.x >> 6][2] = ok; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      for (int w = 1; w < 16; ++w) { lo = fminf(lo, red[w][0]); hi = fmaxf(hi, red[w][1]); ok = fminf(ok, red[w][2]); }
-      trange[0] = lo; trange[1] = hi; trange[2] = ok;
-    }
-    __syncthreads();
-  }
-  float v[7] = {inf, inf, inf, -inf, -inf, -inf, ps.x ? 1.f : trange[2]};
-  const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
-  if (i < items) {
-    for (int e = 0; e < (ps.x ? 1 : 2); ++e) {
-      float px, py, pz, nx, ny, nz;
-      if (ps.x) {
-        load_point(ps, i, px, py, pz);
-      } else {
-        const float tt = trange[e];
-        const float* o = ps.o + (size_t)i * 3;
-        const float* d = ps.d + (size_t)i * 3;
-        px = __fadd_rn(o[0], __fmul_rn(d[0], tt)); py = __fadd_rn(o[1], __fmul_rn(d[1], tt)); pz = __fadd_rn(o[2], __fmul_rn(d[2], tt));
-      }
-      normalise(g, px, py, pz, nx, ny, nz);
-      v[0] = fminf(v[0], nx); v[1] = fminf(v[1], ny); v[2] = fminf(v[2], nz);
-      v[3] = fmaxf(v[3], nx); v[4] = fmaxf(v[4], ny); v[5] = fmaxf(v[5], nz);
-      if (!(isfinite(nx) && isfinite(ny) && isfinite(nz))) v[6] = 0.f;
-    }
-  }
+  // fminf / fmaxf skip a NaN: `finite` records that the box does not cover such a point
+  float v[7] = {nx, ny, nz, nx, ny, nz, (isfinite(nx) && isfinite(ny) && isfinite(nz)) ? 1.f : 0.f};
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
 #pragma unroll
@@ -190,7 +151,6 @@ __global__ __launch_bounds__(1024) void bounds_kernel(PointSrc ps, uint32_t item
     for (int k = 3; k < 6; ++k) v[k] = fmaxf(v[k], __shfl_xor(v[k], o));
     v[6] = fminf(v[6], __shfl_xor(v[6], o));
   }
-  __syncthreads();
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
     for (int k = 0; k < 7; ++k) red[threadIdx.x >> 6][k] = v[k];
@@ -266,15 +226,10 @@ __global__ __launch_bounds__(256) void absmax_kernel(const void* __restrict__ dy
 
 // one workgroup: partial maxima / boxes -> Meta.  `given` (optional): per-level maxima handed in by the caller.
 // Wave w reduces the maxima of levels w, w + 16 (no workgroup barrier); then all threads reduce the boxes.
-// Ray mode with few rays (`direct_rays` > 0): the boxes of the rays' end points are taken right here instead of by a
-// bounds_kernel launch (only below 4096 rays: each box costs six IEEE divisions, and at 16 000 rays one workgroup
-// doing them took 20 us against 8 + 6 us for the two launches).
 __global__ __launch_bounds__(1024) void meta_reduce_kernel(const uint32_t* __restrict__ abs_part, int abs_blocks,
                                                            const float* __restrict__ given, const float* __restrict__ bounds_part,
-                                                           uint32_t nboxes, int L, Meta* __restrict__ meta, PointSrc ps, HashGeom g,
-                                                           uint32_t direct_rays) {
+                                                           uint32_t nboxes, int L, Meta* __restrict__ meta) {
   __shared__ float red[16][7];
-  __shared__ float trange[3];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (int l = wv; l < HBR_MAX_LEVELS; l += 16) {
     uint32_t m = 0;
@@ -288,46 +243,13 @@ __global__ __launch_bounds__(1024) void meta_reduce_kernel(const uint32_t* __res
   }
   const float inf = __uint_as_float(0x7f800000u);
   float v[7] = {inf, inf, inf, -inf, -inf, -inf, 1.f};
-  if (direct_rays) {
-    float lo = inf, hi = -inf, ok = 1.f;
-    for (uint32_t s = threadIdx.x; s < ps.S; s += 1024) {
-      const float tt = ps.t[s];
-      lo = fminf(lo, tt); hi = fmaxf(hi, tt);
-      if (!isfinite(tt)) ok = 0.f;
-    }
+  for (uint32_t s = threadIdx.x; s < nboxes; s += 1024) {  // the stripes' boxes (normalise_kernel)
+    const float* p = bounds_part + (size_t)s * 7;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); ok = fminf(ok, __shfl_xor(ok, o)); }
-    if (lane == 0) { red[wv][0] = lo; red[wv][1] = hi; red[wv][2] = ok; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      for (int w = 1; w < 16; ++w) { lo = fminf(lo, red[w][0]); hi = fmaxf(hi, red[w][1]); ok = fminf(ok, red[w][2]); }
-      trange[0] = lo; trange[1] = hi; trange[2] = ok;
-    }
-    __syncthreads();
-    v[6] = trange[2];
-    for (uint32_t r = threadIdx.x; r < direct_rays; r += 1024) {
-      const float* o = ps.o + (size_t)r * 3;
-      const float* d = ps.d + (size_t)r * 3;
+    for (int k = 0; k < 3; ++k) v[k] = fminf(v[k], p[k]);
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const float tt = trange[e];
-        float nx, ny, nz;
-        normalise(g, __fadd_rn(o[0], __fmul_rn(d[0], tt)), __fadd_rn(o[1], __fmul_rn(d[1], tt)), __fadd_rn(o[2], __fmul_rn(d[2], tt)), nx, ny, nz);
-        v[0] = fminf(v[0], nx); v[1] = fminf(v[1], ny); v[2] = fminf(v[2], nz);
-        v[3] = fmaxf(v[3], nx); v[4] = fmaxf(v[4], ny); v[5] = fmaxf(v[5], nz);
-        if (!(isfinite(nx) && isfinite(ny) && isfinite(nz))) v[6] = 0.f;
-      }
-    }
-    __syncthreads();  // red is reused below
-  } else {
-    for (uint32_t s = threadIdx.x; s < nboxes; s += 1024) {
-      const float* p = bounds_part + (size_t)s * 7;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) v[k] = fminf(v[k], p[k]);
-#pragma unroll
-      for (int k = 3; k < 6; ++k) v[k] = fmaxf(v[k], p[k]);
-      v[6] = fminf(v[6], p[6]);
-    }
+    for (int k = 3; k < 6; ++k) v[k] = fmaxf(v[k], p[k]);
+    v[6] = fminf(v[6], p[6]);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -928,11 +850,8 @@ extern "C" int hbr_hash_encode_bwd(const float* x, const float* rays_o, const fl
   char* wsb = (char*)ws;
   const bool full = ws_bytes >= w.total;  // else: hashed slices for every level, float-atomic flush
   const uint32_t stripes = (N + 1023u) / 1024u;
-  if (!reuse_coords) hipLaunchKernelGGL(normalise_kernel, dim3(stripes), dim3(1024), 0, st, ps, N, g, (float*)(wsb + w.xnorm));
-  const uint32_t items = ps.x ? N : (uint32_t)R;            // boxes: per point, or per ray (two end points each)
-  const uint32_t nboxes = (items + 1023u) / 1024u;          // <= stripes
-  const uint32_t direct_rays = (!ps.x && R <= 4096) ? (uint32_t)R : 0u;  // few rays: meta_reduce_kernel takes their boxes itself
-  if (!direct_rays && !reuse_coords) hipLaunchKernelGGL(bounds_kernel, dim3(nboxes), dim3(1024), 0, st, ps, items, g, (float*)(wsb + w.bounds_part));
+  if (!reuse_coords)  // coordinates in scatter order + one bounding box per stripe
+    hipLaunchKernelGGL(normalise_kernel, dim3(stripes), dim3(1024), 0, st, ps, N, g, (float*)(wsb + w.xnorm), (float*)(wsb + w.bounds_part));
   uint32_t* abs_part = (uint32_t*)(wsb + w.abs_part);
   int abs_blocks = 0;
   if (!dy_absmax) {
@@ -945,7 +864,7 @@ extern "C" int hbr_hash_encode_bwd(const float* x, const float* rays_o, const fl
     }
   }
   hipLaunchKernelGGL(meta_reduce_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)abs_part, abs_blocks, dy_absmax,
-                     (const float*)(wsb + w.bounds_part), nboxes, L, (Meta*)(wsb + w.meta), ps, g, direct_rays);
+                     (const float*)(wsb + w.bounds_part), stripes, L, (Meta*)(wsb + w.meta));
 #define HBR_BWD(P, LY, DT) rc = launch_lds<P, LY, DT>(st, N, dy, dy_stride, g, dtables, wsb, w, full)
   if (g.pow2) {
     if (layout == HBR_LAYOUT_PLANAR) { if (dy_dtype == HBR_F32) HBR_BWD(true, HBR_LAYOUT_PLANAR, HBR_F32); else HBR_BWD(true, HBR_LAYOUT_PLANAR, HBR_BF16); }

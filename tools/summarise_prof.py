@@ -12,7 +12,7 @@ dst = os.path.join(root, "profiles")
 # bench.py's four timed spans -> the kernels each one launches (K2 and K4 are short sequences of kernels; a span's HBM
 # traffic is the sum over its kernels, one launch of each per step)
 KERNELS = {"hash_fwd": ["hash_fwd_kernel"],
-           "hash_bwd": ["normalise_kernel", "bounds_kernel", "absmax_", "meta_reduce_kernel", "hash_scatter_kernel", "dense_scatter_kernel",
+           "hash_bwd": ["normalise_kernel", "absmax_", "meta_reduce_kernel", "hash_scatter_kernel", "dense_scatter_kernel",
                         "slab_reduce_kernel"],
            "mlp_fwd": ["mlp_fwd_kernel"], "mlp_bwd": ["mlp_bwd_fused_kernel", "mlp_dw_reduce_kernel"]}
 
