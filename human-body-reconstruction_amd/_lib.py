@@ -12,6 +12,8 @@ LIB_PATH = os.environ.get("HBR_LIB") or os.path.join(_HERE, "libhbr_hip.so")
 ROWS, PLANAR = 0, 1
 F32, BF16 = 0, 1
 IMAGE_READY = 0x100  # hbr_hip.h: OR-ed into hbr_mlp_bwd's precision
+OVERWRITE = 0x200    # hbr_hip.h: OR-ed into hbr_hash_encode_bwd's algo / hbr_mlp_bwd's precision
+EUNSUPPORTED = -2
 MLP_PARAM_FLOATS = 14227
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float

@@ -653,7 +653,7 @@ __global__ __launch_bounds__(256) void dense_scatter_kernel(HashGeom g, int dchu
 // one summation order.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int chunks, HashGeom g, int fixbits,
                                                           int dense_levels, const Meta* __restrict__ meta, const unsigned long long* __restrict__ g64,
-                                                          float* __restrict__ dtables) {
+                                                          float* __restrict__ dtables, bool overwrite) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (l, row)
   const int L = g.L;
   const int64_t T = g.T;
@@ -682,8 +682,8 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
       s1 = __fadd_rn(s1, p0[(size_t)c * chunk_stride + T]);
     }
   }
-  float2* d = (float2*)dtables + i;
-  float2 v = *d;
+  float2* d = (float2*)dtables + i;  // this thread is the row's only writer
+  float2 v = overwrite ? make_float2(0.f, 0.f) : *d;
   v.x = __fadd_rn(v.x, s0); v.y = __fadd_rn(v.y, s1);
   *d = v;
 }
@@ -764,7 +764,7 @@ static void launch_absmax(hipStream_t st, const void* dy, uint32_t N, int64_t st
 
 template <bool POW2, int LAYOUT, int DTYPE>
 static int launch_lds(hipStream_t st, uint32_t N, const void* dy, int64_t stride, const HashGeom& g, float* dtables, char* ws,
-                      const Workspace& w, bool full) {
+                      const Workspace& w, bool full, bool overwrite) {
   const int spl = lds_slices(g.T);
   const int chunks = lds_chunks(N, spl);
   const int fixbits = fix_bits_for(N);
@@ -789,7 +789,7 @@ static int launch_lds(hipStream_t st, uint32_t N, const void* dy, int64_t stride
   if (full) {
     const int64_t rows = (int64_t)g.L * g.T;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((uint32_t)((rows + 255) / 256)), dim3(256), 0, st, (const float*)slabs, chunks, g,
-                       fixbits, dl, meta, (const unsigned long long*)(ws + w.g64), dtables);
+                       fixbits, dl, meta, (const unsigned long long*)(ws + w.g64), dtables, overwrite);
   }
   return HBR_OK;
 }
@@ -818,6 +818,8 @@ extern "C" int hbr_hash_encode_bwd(const float* x, const float* rays_o, const fl
   if (layout != HBR_LAYOUT_ROWS && layout != HBR_LAYOUT_PLANAR) return HBR_EINVAL;
   if (dy_dtype != HBR_F32 && dy_dtype != HBR_BF16) return HBR_EINVAL;
   if (layout == HBR_LAYOUT_ROWS && dy_stride < (int64_t)L * F) return HBR_EINVAL;
+  const bool overwrite = (algo & HBR_OVERWRITE) != 0;  // write dtables instead of accumulating (hbr_hip.h)
+  algo &= ~HBR_OVERWRITE;
   if (algo < 0 || algo > 3) return HBR_EINVAL;
   const bool reuse_coords = algo == 3;  // algo 3 = algo 2, the coordinates (and their boxes) of the previous call on `ws` still valid
   if (reuse_coords) algo = 2;
@@ -828,7 +830,7 @@ extern "C" int hbr_hash_encode_bwd(const float* x, const float* rays_o, const fl
   uint32_t N;
   rc = check_points(x, rays_o, rays_d, t, R, S, ps, N);
   if (rc) return rc;
-  if (N == 0) return HBR_OK;
+  if (N == 0) return overwrite ? HBR_EUNSUPPORTED : HBR_OK;  // nothing would write the rows
   hipStream_t st = (hipStream_t)stream;
   // The LDS kernels shift row offsets left by 3 in 32 bits and need their workspace.  Auto picks them once there are
   // enough points to amortise the fixed 128 KiB flush per workgroup and the workspace is there; asked for explicitly
@@ -841,6 +843,7 @@ extern "C" int hbr_hash_encode_bwd(const float* x, const float* rays_o, const fl
     if (!ws_ok) return HBR_EWORKSPACE;
   }
   if (algo == 0) algo = (N >= 65536u && ws_ok) ? 2 : 1;
+  if (overwrite && (algo == 1 || ws_bytes < w.total)) return HBR_EUNSUPPORTED;  // float atomics add to what is there
   if (algo == 1) {
     rc = launch_hash_bwd_atomic(st, ps, N, dy, layout, dy_stride, dy_dtype, g, dtables);
     if (rc) return rc;
@@ -865,7 +868,7 @@ extern "C" int hbr_hash_encode_bwd(const float* x, const float* rays_o, const fl
   }
   hipLaunchKernelGGL(meta_reduce_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)abs_part, abs_blocks, dy_absmax,
                      (const float*)(wsb + w.bounds_part), stripes, L, (Meta*)(wsb + w.meta));
-#define HBR_BWD(P, LY, DT) rc = launch_lds<P, LY, DT>(st, N, dy, dy_stride, g, dtables, wsb, w, full)
+#define HBR_BWD(P, LY, DT) rc = launch_lds<P, LY, DT>(st, N, dy, dy_stride, g, dtables, wsb, w, full, overwrite)
   if (g.pow2) {
     if (layout == HBR_LAYOUT_PLANAR) { if (dy_dtype == HBR_F32) HBR_BWD(true, HBR_LAYOUT_PLANAR, HBR_F32); else HBR_BWD(true, HBR_LAYOUT_PLANAR, HBR_BF16); }
     else { if (dy_dtype == HBR_F32) HBR_BWD(true, HBR_LAYOUT_ROWS, HBR_F32); else HBR_BWD(true, HBR_LAYOUT_ROWS, HBR_BF16); }

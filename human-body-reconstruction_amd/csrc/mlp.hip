@@ -878,7 +878,7 @@ __global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(const float* __restr
 // a tile of a two-tile layer, and the 4 waves x 2 lane halves that hold partial sums of one bias row - so ONE of them
 // (the "leader": the even wave / wave 0's lower half) adds up its siblings in a fixed order and the others return:
 // every parameter has exactly one writer and one summation order, i.e. the MLP gradient is bitwise reproducible.
-__global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(const float* __restrict__ tot, float* __restrict__ dparams, bool swapped) {
+__global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(const float* __restrict__ tot, float* __restrict__ dparams, bool swapped, bool overwrite) {
   const int e = blockIdx.x * 256 + threadIdx.x;  // (wave, register, lane) of the slab layout
   if (e >= kSlabWg) return;
   const int lane = e & 63, r = (e >> 6) % kSlabRegs, wv = e / kSlabWave, h = lane >> 5;
@@ -898,7 +898,7 @@ __global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(const float* __res
 #pragma unroll
     for (int k = 1; k < 4; ++k) v += tot[e + k * kSlabWave] + tot[e + k * kSlabWave + 32];
   }
-  dparams[off] += v;  // the only writer of this address
+  dparams[off] = overwrite ? v : dparams[off] + v;  // the only writer of this address
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1422,7 +1422,7 @@ static int launch_fwd(int dt, uint32_t blocks, hipStream_t st, const char* img, 
 
 template <class P, int LAYOUT, int DT, bool WLDS>
 static int launch_bwd_fused(uint32_t ntiles, hipStream_t st, const char* img, FeatSrc fs, PeSrc ps, const float* dout,
-                            DFeatDst dfd, float* dparams, float* absmax_out) {
+                            DFeatDst dfd, float* dparams, float* absmax_out, bool overwrite) {
   using T = Tab<P>;
   const int lds = Xch<P>::BYTES + (WLDS ? T::IMG_BYTES : 0);
   uint32_t blocks = (ntiles + 3) / 4;
@@ -1435,16 +1435,16 @@ static int launch_bwd_fused(uint32_t ntiles, hipStream_t st, const char* img, Fe
   float* tot = slabs + (size_t)kMaxBwdBlocks * kSlabWg + 16 * (size_t)kAbsWaves;  // behind the maxima
   hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(kSlabWg / 32 + (want_abs ? 16 : 0)), dim3(256), 0, st, (const float*)slabs, (int)blocks,
                      tot, (const uint32_t*)dfd.abs_part, absmax_out, kXchSwapped<P>);
-  hipLaunchKernelGGL(mlp_dw_finalize_kernel, dim3((kSlabWg + 255) / 256), dim3(256), 0, st, (const float*)tot, dparams, kXchSwapped<P>);
+  hipLaunchKernelGGL(mlp_dw_finalize_kernel, dim3((kSlabWg + 255) / 256), dim3(256), 0, st, (const float*)tot, dparams, kXchSwapped<P>, overwrite);
   return HBR_OK;
 }
 
 // single pass, dW tiles shared by the four waves of a workgroup through an LDS fragment exchange
 template <int LAYOUT, int DT>
 static int launch_bwd(int precision, uint32_t ntiles, hipStream_t st, const char* img, FeatSrc fs, PeSrc ps, const float* dout,
-                      DFeatDst dfd, float* dparams, float* absmax_out) {
-  if (precision == HBR_BF16) return launch_bwd_fused<PBf16, LAYOUT, DT, true>(ntiles, st, img, fs, ps, dout, dfd, dparams, absmax_out);
-  return launch_bwd_fused<PF32, LAYOUT, DT, false>(ntiles, st, img, fs, ps, dout, dfd, dparams, absmax_out);
+                      DFeatDst dfd, float* dparams, float* absmax_out, bool overwrite) {
+  if (precision == HBR_BF16) return launch_bwd_fused<PBf16, LAYOUT, DT, true>(ntiles, st, img, fs, ps, dout, dfd, dparams, absmax_out, overwrite);
+  return launch_bwd_fused<PF32, LAYOUT, DT, false>(ntiles, st, img, fs, ps, dout, dfd, dparams, absmax_out, overwrite);
 }
 
 // HBR_MLP_ADDR64 (any value) in the environment sends every call down the 64-bit addressing path that sizes beyond
@@ -1535,11 +1535,12 @@ extern "C" int hbr_mlp_bwd(const void* feat, int layout, int64_t feat_stride, in
   // HBR_IMAGE_READY: `ws` still holds the fragment image hbr_mlp_fwd / hbr_mlp_bwd built from THESE params at this
   // precision (a training step's forward, then its backward): skip the 5 us pack launch
   const bool image_ready = (precision & HBR_IMAGE_READY) != 0;
-  precision &= ~HBR_IMAGE_READY;
+  const bool overwrite = (precision & HBR_OVERWRITE) != 0;  // dparams written instead of accumulated into
+  precision &= ~(HBR_IMAGE_READY | HBR_OVERWRITE);
   int rc = check_common(feat, layout, feat_stride, feat_dtype, viewdirs_enc, N, group, params, precision, ws, ws_bytes);
   if (rc) return rc;
   if (!dout || !dparams || ((uintptr_t)dout & 15)) return HBR_EINVAL;
-  if (N == 0) return HBR_OK;
+  if (N == 0) return overwrite ? HBR_EUNSUPPORTED : HBR_OK;  // nothing would write dparams
   hipStream_t st = (hipStream_t)stream;
   FeatSrc fs{feat, feat_stride, (uint32_t)N, addr32_ok(N, group)};
   PeSrc ps{viewdirs_enc, (uint32_t)group};
@@ -1551,11 +1552,11 @@ extern "C" int hbr_mlp_bwd(const void* feat, int layout, int64_t feat_stride, in
     else pack<PF32>(params, img, st);
   }
   if (layout == HBR_LAYOUT_PLANAR) {
-    if (feat_dtype == HBR_F32) rc = launch_bwd<HBR_LAYOUT_PLANAR, HBR_F32>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams, dfeat_absmax);
-    else rc = launch_bwd<HBR_LAYOUT_PLANAR, HBR_BF16>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams, dfeat_absmax);
+    if (feat_dtype == HBR_F32) rc = launch_bwd<HBR_LAYOUT_PLANAR, HBR_F32>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams, dfeat_absmax, overwrite);
+    else rc = launch_bwd<HBR_LAYOUT_PLANAR, HBR_BF16>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams, dfeat_absmax, overwrite);
   } else {
-    if (feat_dtype == HBR_F32) rc = launch_bwd<HBR_LAYOUT_ROWS, HBR_F32>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams, dfeat_absmax);
-    else rc = launch_bwd<HBR_LAYOUT_ROWS, HBR_BF16>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams, dfeat_absmax);
+    if (feat_dtype == HBR_F32) rc = launch_bwd<HBR_LAYOUT_ROWS, HBR_F32>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams, dfeat_absmax, overwrite);
+    else rc = launch_bwd<HBR_LAYOUT_ROWS, HBR_BF16>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams, dfeat_absmax, overwrite);
   }
   if (rc) return rc;
   HBR_RETURN_IF_LAUNCH_FAILED();

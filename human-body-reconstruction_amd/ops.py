@@ -12,7 +12,7 @@ from typing import Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, IMAGE_READY, PLANAR, ROWS, HbrError, check, lib, require_gpu
+from ._lib import BF16, EUNSUPPORTED, F32, IMAGE_READY, OVERWRITE, PLANAR, ROWS, HbrError, check, lib, require_gpu
 
 _ws_cache = {}
 _MAX_SCATTER_WS = 8 << 30  # largest K2 workspace allocated for the reproducible (slab) flush
@@ -117,8 +117,10 @@ def hash_encode_fwd(geom: HashGeom, tables: torch.Tensor, x: Optional[torch.Tens
 
 
 def hash_encode_bwd(geom: HashGeom, dy: torch.Tensor, dtables: torch.Tensor, x: Optional[torch.Tensor] = None, rays=None,
-                    layout: int = ROWS, algo: int = 0, dy_absmax: Optional[torch.Tensor] = None, deterministic: bool = True):
-    """Accumulates into dtables [L,T,F] fp32.  algo 0 = auto (LDS fixed-point kernels from 65536 points), 1 = global
+                    layout: int = ROWS, algo: int = 0, dy_absmax: Optional[torch.Tensor] = None, deterministic: bool = True,
+                    overwrite: bool = False):
+    """Accumulates into dtables [L,T,F] fp32 - or, with `overwrite`, leaves exactly this call's gradient there whatever
+    the buffer held (written by the kernels where each row has one writer, else zeroed here first).  algo 0 = auto (LDS fixed-point kernels from 65536 points), 1 = global
     float atomics, 2 = LDS kernels, 3 = LDS kernels re-using the coordinates the previous call (same points, same
     stream) left in the workspace.  `deterministic` (algo 2): reduce the chunk partials in a fixed order (full
     workspace) instead of with float atomics.  `dy_absmax` [L] fp32 on the device: per-level max |dy| if the caller
@@ -138,6 +140,8 @@ def hash_encode_bwd(geom: HashGeom, dy: torch.Tensor, dtables: torch.Tensor, x: 
         raise HbrError("dtables must be a contiguous float32 [L,T,F] buffer")
     stride = dy.shape[-1] if layout == ROWS else 0
     if R * S == 0:
+        if overwrite:
+            dtables.zero_()
         return dtables
     sc, mu = geom.c_args()
     nws = lib().hbr_hash_bwd_workspace_bytes(R * S, geom.L, geom.T, geom.F, algo) if deterministic else 0
@@ -152,9 +156,14 @@ def hash_encode_bwd(geom: HashGeom, dy: torch.Tensor, dtables: torch.Tensor, x: 
         ws = _workspace("hash_bwd", nws, dy.device) if nws else None
     if dy_absmax is not None:
         dy_absmax = _f32c(dy_absmax)
-    check(lib().hbr_hash_encode_bwd(_ptr(x), _ptr(o), _ptr(d), _ptr(t), R, S, dy.data_ptr(), layout, stride, dtype, _ptr(dy_absmax),
-                                    sc, mu, geom.sigma, geom.L, geom.T, geom.F, dtables.data_ptr(), algo, _ptr(ws), nws, _stream()),
-          "hbr_hash_encode_bwd")
+    def call(a):
+        return lib().hbr_hash_encode_bwd(_ptr(x), _ptr(o), _ptr(d), _ptr(t), R, S, dy.data_ptr(), layout, stride, dtype, _ptr(dy_absmax),
+                                         sc, mu, geom.sigma, geom.L, geom.T, geom.F, dtables.data_ptr(), a, _ptr(ws), nws, _stream())
+    rc = call(algo | OVERWRITE) if overwrite else call(algo)
+    if overwrite and rc == EUNSUPPORTED:  # a path that adds to what is there (float atomics): zero, then accumulate
+        dtables.zero_()
+        rc = call(algo)
+    check(rc, "hbr_hash_encode_bwd")
     return dtables
 
 
@@ -196,10 +205,11 @@ def mlp_fwd(feat: torch.Tensor, layout: int, viewdirs_enc: torch.Tensor, group: 
 
 def mlp_bwd(feat: torch.Tensor, layout: int, viewdirs_enc: torch.Tensor, group: int, params: torch.Tensor, precision: int,
             dout: torch.Tensor, dparams: torch.Tensor, need_dfeat: bool = True, absmax_out: Optional[torch.Tensor] = None,
-            image_ready: bool = False):
+            image_ready: bool = False, overwrite: bool = False):
     """absmax_out: optional [16] fp32 device tensor that receives max |d feat| per level (hash_encode_bwd's dy_absmax).
     image_ready: the last MLP call on this stream was `mlp_fwd` / `mlp_bwd` with the SAME params and precision (the
-    workspace still holds their fragment image) - skips the repack."""
+    workspace still holds their fragment image) - skips the repack.  overwrite: dparams receives this call's gradient
+    instead of accumulating it (no zeroing needed)."""
     N, stride, dtype = _feat_desc(feat, layout)
     # d feat takes feat's layout INCLUDING its row stride (the kernel addresses both with feat_stride): a strided rows
     # view such as y[:, :32] of an [N,36] buffer gets a gradient buffer with the same 36-element pitch
@@ -209,9 +219,11 @@ def mlp_bwd(feat: torch.Tensor, layout: int, viewdirs_enc: torch.Tensor, group: 
     if N == 0:
         if absmax_out is not None:
             absmax_out.zero_()
+        if overwrite:
+            dparams.zero_()
         return dfeat
     check(lib().hbr_mlp_bwd(feat.data_ptr(), layout, stride, dtype, viewdirs_enc.data_ptr(), N, group, params.data_ptr(),
-                            precision | (IMAGE_READY if image_ready else 0), dout.data_ptr(), _ptr(dfeat), _ptr(absmax_out), dparams.data_ptr(), ws.data_ptr(), ws.numel(),
+                            precision | (IMAGE_READY if image_ready else 0) | (OVERWRITE if overwrite else 0), dout.data_ptr(), _ptr(dfeat), _ptr(absmax_out), dparams.data_ptr(), ws.data_ptr(), ws.numel(),
                             _stream()), "hbr_mlp_bwd")
     return dfeat
 

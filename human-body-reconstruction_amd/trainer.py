@@ -122,12 +122,13 @@ class HashNeRFTrainer:
         loss, dCr = ops.mse2_loss(Cr, gt)
         d_out = torch.empty_like(out)
         ops.composite_bwd(t, out.data_ptr(), 4, out.data_ptr() + 12, 4, dn, R, S, dCr, d_out.data_ptr(), d_out.data_ptr() + 12)
-        self.grad.zero_()
+        # No memset of the 8 MiB gradient buffer: K4 and K2 WRITE their outputs (`overwrite`; where K2 runs a path that
+        # can only accumulate, ops zeroes that slice itself).  The padding behind the MLP block is never written.
         # K4 also reports max |d feat| per level: K2's fixed-point scale, without K2 re-reading the buffer for it
         amax = self._amax if g.L == 16 else None
         # (image_ready: the workspace still holds the weight fragments this step's mlp_fwd packed from self.flat)
         dfeat = self._timed("mlp_bwd", lambda: ops.mlp_bwd(feat, PLANAR, pe, S, self.flat, self.precision, d_out, self.g_mlp,
-                                                           absmax_out=amax, image_ready=True))
+                                                           absmax_out=amax, image_ready=True, overwrite=True))
         if self.split_scatter and g.L >= 2:
             # The step's one all-reduce, issued in three pieces that partition the flat gradient buffer: the MLP block
             # (final after K4), then the upper half of the levels while the lower half's scatter is still running.
@@ -145,14 +146,14 @@ class HashNeRFTrainer:
                     sub = ops.HashGeom(g.scales[lo:hi], g.mu, g.sigma, g.T, g.F)
                     ops.hash_encode_bwd(sub, dfeat[lo:hi], self.g_tab[lo:hi], rays=rays, layout=PLANAR,
                                         algo=(2 if k == 0 else 3) if lds else self.scatter_algo,
-                                        dy_absmax=None if amax is None else amax[lo:hi])
+                                        dy_absmax=None if amax is None else amax[lo:hi], overwrite=True)
                     red.launch(piece)
 
             self._timed("hash_bwd", scatter_halves)
             red.finish()
         else:
             self._timed("hash_bwd", lambda: ops.hash_encode_bwd(g, dfeat, self.g_tab, rays=rays, layout=PLANAR, algo=self.scatter_algo,
-                                                                dy_absmax=amax))
+                                                                dy_absmax=amax, overwrite=True))
             # the one collective of the step
             if self.world > 1:
                 torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)

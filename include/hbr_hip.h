@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define HBR_VERSION 201 /* 0.2.1: HBR_IMAGE_READY */
+#define HBR_VERSION 202 /* 0.2.2: HBR_IMAGE_READY, HBR_OVERWRITE */
 
 enum {
   HBR_OK = 0,
@@ -46,6 +46,12 @@ enum { HBR_F32 = 0, HBR_BF16 = 1 };
  * hbr_mlp_fwd / hbr_mlp_bwd call built from the same `params` at the same precision (forward then backward of one
  * training step), so the backward need not pack it again. */
 enum { HBR_IMAGE_READY = 0x100 };
+/* OR-ed into hbr_hash_encode_bwd's `algo` and hbr_mlp_bwd's `precision`: the gradient outputs (dtables / dparams) are
+ * WRITTEN instead of accumulated into, so the caller need not zero them first (a training step's 8 MiB memset).
+ * hbr_hash_encode_bwd honours it only where every row has exactly one writer - the LDS kernels with the full
+ * workspace (algo 0 / 2 / 3 resolving to that) - and returns HBR_EUNSUPPORTED otherwise, before launching anything:
+ * the caller then zeroes the buffer and calls again without the flag. */
+enum { HBR_OVERWRITE = 0x200 };
 
 int hbr_version(void);
 const char* hbr_strerror(int code);

@@ -499,3 +499,46 @@ def test_mlp_bwd_reuses_the_forward_image(ops, precision):
     ops.mlp_fwd(feat, PLANAR, pe, 1, P2, precision)   # a different image in the workspace
     stale = bwd(True)
     assert not torch.equal(stale[1], ref[1])
+
+
+def test_overwrite_mode_equals_accumulating_into_zeros(ops):
+    """HBR_OVERWRITE (the trainer's way of not zeroing 8 MiB per step): K2 and K4 leave exactly this call's gradient in
+    buffers that held garbage - bit for bit what accumulating into zeros gives - on the LDS path (rows written by the
+    slab reduce), on the float-atomic path (ops zeroes first) and for an empty batch."""
+    from hbr_amd._lib import BF16, PLANAR
+    R, S, T = 1024, 64, 2 ** 12            # 65 536 points: the LDS kernels
+    o, d, t, mn, sig, sc, geom = _scene(ops, R, S, T, seed=31)
+    rays = (o.to(DEV), d.to(DEV), t.to(DEV))
+    g = torch.Generator().manual_seed(4)
+    dy = (torch.randn((16, R * S, 2), generator=g) * 1e-3).bfloat16().to(DEV)
+    for algo in (2, 1, 0):
+        ref = ops.hash_encode_bwd(geom, dy, torch.zeros((16, T, 2), device=DEV), rays=rays, layout=PLANAR, algo=algo)
+        junk = torch.full((16, T, 2), 7.5, device=DEV)
+        got = ops.hash_encode_bwd(geom, dy, junk, rays=rays, layout=PLANAR, algo=algo, overwrite=True)
+        if algo == 1:   # float atomics: order-dependent rounding
+            assert torch.allclose(got, ref, rtol=1e-4, atol=1e-5 * float(ref.abs().max()))
+        else:
+            assert torch.equal(got, ref), algo
+    few = (rays[0][:8], rays[1][:8], rays[2])   # 512 points: the float-atomic kernel, zeroed by ops
+    ref = ops.hash_encode_bwd(geom, dy[:, :512].contiguous(), torch.zeros((16, T, 2), device=DEV), rays=few, layout=PLANAR)
+    got = ops.hash_encode_bwd(geom, dy[:, :512].contiguous(), torch.full((16, T, 2), -3.0, device=DEV), rays=few, layout=PLANAR, overwrite=True)
+    assert torch.allclose(got, ref, rtol=1e-4, atol=1e-5 * float(ref.abs().max())) and float(got.abs().max()) < 1.0
+    none = (rays[0][:0], rays[1][:0], rays[2])
+    assert float(ops.hash_encode_bwd(geom, dy[:, :0].contiguous(), torch.ones((16, T, 2), device=DEV), rays=none, layout=PLANAR,
+                                     overwrite=True).abs().max()) == 0.0
+
+    N = 2000
+    feat = (torch.randn((16, N, 2), generator=g) * 0.3).bfloat16().to(DEV)
+    pe = ops.dir_encode(torch.nn.functional.normalize(torch.randn((N, 3), generator=g), dim=1).to(DEV), 4)
+    dout = torch.randn((N, 4), generator=g).to(DEV)
+    P = torch.cat([v.reshape(-1) for v in ref_cpu.mlp_init(6).values()]).to(DEV)
+    for prec in (BF16, 0):
+        f = feat if prec == BF16 else feat.float()
+        ref = torch.zeros_like(P)
+        ops.mlp_bwd(f, PLANAR, pe, 1, P, prec, dout, ref)
+        got = torch.full_like(P, 9.25)
+        ops.mlp_bwd(f, PLANAR, pe, 1, P, prec, dout, got, overwrite=True)
+        assert torch.equal(got, ref), prec
+    got = torch.ones_like(P)
+    ops.mlp_bwd(feat[:, :0].contiguous(), PLANAR, pe[:0], 1, P, BF16, dout[:0], got, overwrite=True)
+    assert float(got.abs().max()) == 0.0
