@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "hash_common.h"
+#include "wave_reduce.h"
 
 namespace hbr {
 
@@ -143,23 +144,24 @@ __global__ __launch_bounds__(1024) void normalise_kernel(PointSrc ps, uint32_t N
   q[0] = nx; q[1] = ny; q[2] = nz;
   // fminf / fmaxf skip a NaN: `finite` records that the box does not cover such a point
   float v[7] = {nx, ny, nz, nx, ny, nz, (isfinite(nx) && isfinite(ny) && isfinite(nz)) ? 1.f : 0.f};
+  auto lo = [](float a, float b) { return fminf(a, b); };
+  auto hi = [](float a, float b) { return fmaxf(a, b); };
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
+  for (int k = 0; k < 3; ++k) v[k] = wave_reduce(v[k], lo);  // DPP: 42 __shfl_xor (ds_bpermute) made the kernel LDS-bound
 #pragma unroll
-    for (int k = 0; k < 3; ++k) v[k] = fminf(v[k], __shfl_xor(v[k], o));
-#pragma unroll
-    for (int k = 3; k < 6; ++k) v[k] = fmaxf(v[k], __shfl_xor(v[k], o));
-    v[6] = fminf(v[6], __shfl_xor(v[6], o));
-  }
+  for (int k = 3; k < 6; ++k) v[k] = wave_reduce(v[k], hi);
+  v[6] = wave_reduce(v[6], lo);
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
     for (int k = 0; k < 7; ++k) red[threadIdx.x >> 6][k] = v[k];
   }
   __syncthreads();
-  if (threadIdx.x < 7) {
-    float r = red[0][threadIdx.x];
-    for (int w = 1; w < 16; ++w) r = (threadIdx.x >= 3 && threadIdx.x < 6) ? fmaxf(r, red[w][threadIdx.x]) : fminf(r, red[w][threadIdx.x]);
-    part[(size_t)blockIdx.x * 7 + threadIdx.x] = r;
+  // the 16 waves' values of entry k meet in one row of 16 lanes (threads 16 k .. 16 k + 15): one more row reduction
+  if (threadIdx.x < 128) {  // whole waves, so every row is fully active (row 7 idles on a copy of entry 6)
+    const int k = min((int)(threadIdx.x >> 4), 6), w = threadIdx.x & 15;
+    const float x = red[w][k];
+    const float r = (k >= 3 && k < 6) ? row_reduce(x, hi) : row_reduce(x, lo);
+    if (w == 0 && threadIdx.x < 112) part[(size_t)blockIdx.x * 7 + k] = r;
   }
 }
 
