@@ -2,32 +2,17 @@
 // 2*MSE loss of train_hash2.py:221.  One wavefront per ray: the S samples are swept in chunks of 64
 // lanes, the transmittance prefix is a wave-level scan (no LDS round trip for the scan itself).
 #include "hbr_common.h"
+#include "wave_reduce.h"
 
 namespace hbr {
 
 constexpr int kRaysPerBlock = 4;
 constexpr int kMaxChunks = 64;  // S <= 4096
 
-__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    float o = __shfl_up(v, d, 64);
-    if (lane >= d) v += o;
-  }
-  return v;
-}
-__device__ __forceinline__ float wave_incl_scan_rev(float v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    float o = __shfl_down(v, d, 64);
-    if (lane + d < 64) v += o;
-  }
-  return v;
-}
+// 64-lane sums and prefix / suffix sums by DPP row operations (wave_reduce.h): `__shfl_*` compiles to ds_bpermute,
+// ~42 of them per ray in the backward kernel, which made it LDS-bound (17 us for 11 us of HBM traffic).
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
+  return wave_reduce(v, [](float a, float b) { return a + b; });
 }
 
 struct RayIn {
@@ -66,10 +51,8 @@ __global__ __launch_bounds__(kRaysPerBlock * 64) void composite_fwd_kernel(RayIn
     float delta;
     bool live;
     const float p = sample_p(in, r, s, dn, delta, live);
-    const float incl = wave_incl_scan(p, lane);
-    float excl = __shfl_up(incl, 1, 64);
-    if (lane == 0) excl = 0.f;
-    const float Tr = expf(-(carry + excl));      // helper.py:93-95: exclusive transmittance, T_0 = 1
+    const WaveScan sc = wave_prefix_sum(p, lane);
+    const float Tr = expf(-(carry + sc.excl));   // helper.py:93-95: exclusive transmittance, T_0 = 1
     const float alpha = 1.f - expf(-p);          // :91
     const float w = Tr * alpha;                  // :102
     if (s < in.S) {
@@ -77,7 +60,7 @@ __global__ __launch_bounds__(kRaysPerBlock * 64) void composite_fwd_kernel(RayIn
       c0 += w * c[0]; c1 += w * c[1]; c2 += w * c[2];
       if (wts) wts[r * in.S + s] = w;
     }
-    carry += __shfl(incl, 63, 64);
+    carry += sc.total;
   }
   c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2);
   if (lane == 0) {
@@ -116,10 +99,7 @@ __global__ __launch_bounds__(kRaysPerBlock * 64) void composite_bwd_kernel(RayIn
     float delta;
     bool live;
     const float p = sample_p(in, r, s, dn, delta, live);
-    const float incl = wave_incl_scan(p, lane);
-    float excl = __shfl_up(incl, 1, 64);
-    if (lane == 0) excl = 0.f;
-    const float Tr = expf(-(chunk_carry[wv][c] + excl));
+    const float Tr = expf(-(chunk_carry[wv][c] + wave_prefix_sum(p, lane).excl));
     const float e = expf(-p);
     const float w = Tr * (1.f - e);
     float g = 0.f;
@@ -129,10 +109,8 @@ __global__ __launch_bounds__(kRaysPerBlock * 64) void composite_bwd_kernel(RayIn
       g = g0 * col[0] + g1 * col[1] + g2 * col[2];
     }
     const float gw = g * w;
-    const float rincl = wave_incl_scan_rev(gw, lane);
-    float rexcl = __shfl_down(rincl, 1, 64);
-    if (lane == 63) rexcl = 0.f;
-    const float dp = g * Tr * e - (suffix + rexcl);
+    const WaveScan rs = wave_suffix_sum(gw, lane);
+    const float dp = g * Tr * e - (suffix + rs.excl);
     if (s < in.S) {
       // nothing flows back through a sample the occupancy grid masked out (its sigma/rgb are constants, not MLP outputs)
       const bool kept = !keep || keep[r * in.S + s];
@@ -140,7 +118,7 @@ __global__ __launch_bounds__(kRaysPerBlock * 64) void composite_bwd_kernel(RayIn
       float* dc = d_rgb + (r * in.S + s) * in.rgb_stride;
       dc[0] = kept ? w * g0 : 0.f; dc[1] = kept ? w * g1 : 0.f; dc[2] = kept ? w * g2 : 0.f;
     }
-    suffix += __shfl(rincl, 0, 64);
+    suffix += rs.total;
   }
 }
 

@@ -30,4 +30,49 @@ __device__ __forceinline__ float wave_reduce(float v, Op op) {
   return op(op(a, b), op(c, d));
 }
 
+// ---- 64-lane prefix / suffix sums: Kogge-Stone inside each row of 16 with DPP row shifts (a lane without a source
+// keeps `old` = 0), then the three / four row totals by v_readlane.  ~14 VALU + 4 readlanes instead of 7 ds_bpermute.
+template <int CTRL>
+__device__ __forceinline__ float dpp_or_zero(float v) {  // lanes whose source falls outside the row read 0
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+struct WaveScan {
+  float incl, excl, total;
+};
+__device__ __forceinline__ float lane_value(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+// incl[i] = sum_{k<=i} v[k], excl[i] = sum_{k<i} v[k]
+__device__ __forceinline__ WaveScan wave_prefix_sum(float v, int lane) {
+  v += dpp_or_zero<0x111>(v);  // row_shr:1
+  v += dpp_or_zero<0x112>(v);  // row_shr:2
+  v += dpp_or_zero<0x114>(v);  // row_shr:4
+  v += dpp_or_zero<0x118>(v);  // row_shr:8
+  const float t0 = lane_value(v, 15), t1 = lane_value(v, 31), t2 = lane_value(v, 47), t3 = lane_value(v, 63);
+  const float t01 = t0 + t1, t012 = t01 + t2;
+  const int row = lane >> 4;
+  const float off = row == 0 ? 0.f : (row == 1 ? t0 : (row == 2 ? t01 : t012));
+  WaveScan r;
+  r.incl = v + off;
+  r.excl = dpp_or_zero<0x111>(v) + off;
+  r.total = t012 + t3;
+  return r;
+}
+// incl[i] = sum_{k>=i} v[k], excl[i] = sum_{k>i} v[k]
+__device__ __forceinline__ WaveScan wave_suffix_sum(float v, int lane) {
+  v += dpp_or_zero<0x101>(v);  // row_shl:1
+  v += dpp_or_zero<0x102>(v);  // row_shl:2
+  v += dpp_or_zero<0x104>(v);  // row_shl:4
+  v += dpp_or_zero<0x108>(v);  // row_shl:8
+  const float t0 = lane_value(v, 0), t1 = lane_value(v, 16), t2 = lane_value(v, 32), t3 = lane_value(v, 48);
+  const float t32 = t3 + t2, t321 = t32 + t1;
+  const int row = lane >> 4;
+  const float off = row == 3 ? 0.f : (row == 2 ? t3 : (row == 1 ? t32 : t321));
+  WaveScan r;
+  r.incl = v + off;
+  r.excl = dpp_or_zero<0x101>(v) + off;
+  r.total = t321 + t0;
+  return r;
+}
+
 }  // namespace hbr
