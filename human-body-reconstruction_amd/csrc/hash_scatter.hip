@@ -253,14 +253,13 @@ __global__ __launch_bounds__(1024) void meta_reduce_kernel(const uint32_t* __res
     for (int k = 3; k < 6; ++k) v[k] = fmaxf(v[k], p[k]);
     v[6] = fminf(v[6], p[6]);
   }
+  auto lo = [](float a, float b) { return fminf(a, b); };
+  auto hi = [](float a, float b) { return fmaxf(a, b); };
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
+  for (int k = 0; k < 3; ++k) v[k] = wave_reduce(v[k], lo);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) v[k] = fminf(v[k], __shfl_xor(v[k], o));
-#pragma unroll
-    for (int k = 3; k < 6; ++k) v[k] = fmaxf(v[k], __shfl_xor(v[k], o));
-    v[6] = fminf(v[6], __shfl_xor(v[6], o));
-  }
+  for (int k = 3; k < 6; ++k) v[k] = wave_reduce(v[k], hi);
+  v[6] = wave_reduce(v[6], lo);
   if (lane == 0) {
 #pragma unroll
     for (int k = 0; k < 7; ++k) red[wv][k] = v[k];
