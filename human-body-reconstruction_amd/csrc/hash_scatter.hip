@@ -700,7 +700,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 // problems still get >= 512 workgroups at 16 levels; at most one chunk per 1024-point stripe; never 2^19 points or
 // more per workgroup.
 static int lds_chunks(int64_t N, int spl) {
-  constexpr int64_t kChunkPoints = 256 * 1024;
+  constexpr int64_t kChunkPoints = 256 * 1024;  // 8 chunks at N = 2 M: 0.578 ms; 6: 0.712, 12: 0.618, 16: 0.622 (tools/k2_time.py)
   constexpr int kMinBlocks = 512, kRefLevels = 16;
   int chunks = (int)((N + kChunkPoints / 2) / kChunkPoints);
   if (chunks > 8) chunks = (chunks + 4) / 8 * 8;  // a multiple of 8: chunk c of every (level, slice, feature) on XCD c % 8

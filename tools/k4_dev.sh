@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # K4 development loop ON THE GPU BOX: the MLP-related GPU tests on the default build, then tools/k4_time.py under a
 # rocprofv3 kernel trace for the default build and for every variant library given.
-# usage: tools/k4_dev.sh <tag> [variant.so ...]      (variants: tools/k4_variant.sh <name> -D... on the CPU side, e.g. the
+# usage: tools/k4_dev.sh <tag> [variant.so ...]      (variants: tools/variant.sh <name> mlp -D... on the CPU side, e.g. the
 # phase-timer builds -DHBR_K4_PROF=1 / =2 read by tools/k4_phases.py)
 set -uo pipefail
 TAG="${1:?tag}"; shift; ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"; OUT="$ROOT/gpurun_out/$TAG"; mkdir -p "$OUT"
