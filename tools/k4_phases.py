@@ -1,5 +1,5 @@
 """Where one wave of the bf16 MLP backward spends its cycles (development tool).  Needs a library built with
--DHBR_K4_PROF=1 (tools/variant.sh prof -DHBR_K4_PROF=1) selected through HBR_LIB: wave 0 of workgroup 0 timestamps
+-DHBR_K4_PROF=1 (tools/variant.sh prof mlp -DHBR_K4_PROF=1) selected through HBR_LIB: wave 0 of workgroup 0 timestamps
 its phase boundaries with the shader clock; this prints the cycles per 32-point tile of every phase."""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
