@@ -18,7 +18,10 @@
 // order - no LDS or global float atomics in the loop (ds_add_f32 costs ~190 cycles per wave-instruction on gfx950).
 //
 // Weights are re-packed into MFMA-fragment order by a tiny kernel on every call (parameters are updated in
-// place by the optimiser between calls; nothing is cached across calls), then held in LDS.
+// place by the optimiser between calls; nothing is cached across calls - except that a step's backward may declare
+// the image its forward packed still valid, HBR_IMAGE_READY), then held in LDS.
+// One wave per SIMD in the backward kernel: everything below that looks like scheduling by hand (requests ahead of a
+// fence, MFMAs pinned between epilogue words, vectors built whole) is there because of it - DESIGN.md section 3.
 #include "hbr_common.h"
 #include <cstdlib>
 #include <type_traits>
@@ -907,8 +910,9 @@ __global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(const float* __res
 // One wave cannot hold all 18 dW tiles (288 registers) next to its working set.  Here every wave runs the whole chain
 // for its own 32-point tile, but owns only ONE dW tile per
 // layer (<= 6 tiles = 96 accumulator registers): it parks a layer's X and dZ fragments in an LDS exchange slot
-// (xch_put), runs the next layer's dense while the others catch up, then the workgroup meets at a barrier and each
-// wave accumulates ITS tile of that layer over the fragments of all four waves (xch_take; K = 128 points per round).
+// (xch_put), meets the workgroup at a barrier, runs the next layer's dense while the owners' transposing reads are in
+// flight, and then accumulates ITS tile of that layer over the fragments of all four waves (Owner; K = 128 points
+// per round) with the dense's ReLU-mask epilogue in the shadow of those MFMAs.
 // bf16: the slot is a [point][feature] image written straight from the orientation-1 fragments and read back with
 // the transposing LDS read; f32: the fragments are transposed with identity MFMAs first (no 32-bit transposing read).  Layers with four dW tiles give one tile to every wave;
 // layers with two give each tile to a pair of waves that split the four sources.  The exchange buffer is double-buffered, so one
@@ -932,8 +936,8 @@ struct Xch {
 // bf16 exchange image: a wave's slot is [32 points][128 features x 2 B] (X in chunks 0..7, dZ in chunks 8..15 of a
 // 256-B row), written straight from the orientation-1 fragments and read back by the dW owners with the transposing
 // LDS read (ds_read_b64_tr_b16), which yields the k = point fragments the wgrad MFMA needs - no identity-MFMA
-// transposes.  16-B chunks are XOR-swizzled by the row (cdna_hip_programming.md T10, image (b)): transposed reads are
-// conflict-free, the 8-B writes 2-way.
+// transposes.  16-B chunks are XOR-swizzled by the row (cdna_hip_programming.md T10, image (b)): the transposed reads
+// and the 16-byte writes (columns in xch_feature order) are conflict-free.
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int xch_off(int row, int chunk) {
   return 256 * row + 16 * (chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)));
