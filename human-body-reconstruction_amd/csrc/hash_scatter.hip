@@ -131,9 +131,12 @@ __device__ __forceinline__ LevelPlan level_plan(const Meta* __restrict__ m, cons
 // The same launch takes the bounding box of its 1024 coordinates: part [block][7] = lo xyz, hi xyz, finite (round 2
 // first took the boxes of the rays' end points in a launch of its own; per point they are exact, cost nothing next to
 // the 12 bytes the thread stores, and that launch is gone).
+// It also clears the dense levels' int64 row tables (`zero`, `zero_vec` 16-byte vectors; 6 MiB at L = 16, T = 2^16),
+// a grid-stride loop of plain stores next to the 24 MB it writes anyway - instead of a 5 us memset launch.
 __global__ __launch_bounds__(1024) void normalise_kernel(PointSrc ps, uint32_t N, HashGeom g, float* __restrict__ out,
-                                                         float* __restrict__ part) {
+                                                         float* __restrict__ part, uint4* __restrict__ zero, size_t zero_vec) {
   __shared__ float red[16][7];
+  for (size_t i = (size_t)blockIdx.x * 1024u + threadIdx.x; i < zero_vec; i += (size_t)gridDim.x * 1024u) zero[i] = make_uint4(0u, 0u, 0u, 0u);
   const uint32_t base = blockIdx.x * 1024u;
   const uint32_t n_raw = base + (threadIdx.x & 63u) * 16u + (threadIdx.x >> 6);
   const uint32_t n = min(n_raw, N - 1);
@@ -765,7 +768,7 @@ static void launch_absmax(hipStream_t st, const void* dy, uint32_t N, int64_t st
 
 template <bool POW2, int LAYOUT, int DTYPE>
 static int launch_lds(hipStream_t st, uint32_t N, const void* dy, int64_t stride, const HashGeom& g, float* dtables, char* ws,
-                      const Workspace& w, bool full, bool overwrite) {
+                      const Workspace& w, bool full, bool overwrite, bool g64_cleared) {
   const int spl = lds_slices(g.T);
   const int chunks = lds_chunks(N, spl);
   const int fixbits = fix_bits_for(N);
@@ -777,7 +780,7 @@ static int launch_lds(hipStream_t st, uint32_t N, const void* dy, int64_t stride
   unsigned long long* dslab = (unsigned long long*)(ws + w.dslab);
   const int dchunks = dense_chunks(N);
   const uint32_t dense_blocks = (uint32_t)(dl * dchunks * 2);
-  if (dl > 0 && hipMemsetAsync(g64, 0, (size_t)dl * g.T * 16, st) != hipSuccess) return HBR_ELAUNCH;
+  if (dl > 0 && !g64_cleared && hipMemsetAsync(g64, 0, (size_t)dl * g.T * 16, st) != hipSuccess) return HBR_ELAUNCH;
   auto kern = hash_scatter_kernel<POW2, LAYOUT, DTYPE>;
   const int lds = dl > 0 ? 2 * kDenseCap * 8 : kSliceRows * 8;
   static_assert(2 * kDenseCap * 8 >= kSliceRows * 8, "the dense table is the larger LDS user");
@@ -854,8 +857,10 @@ extern "C" int hbr_hash_encode_bwd(const float* x, const float* rays_o, const fl
   char* wsb = (char*)ws;
   const bool full = ws_bytes >= w.total;  // else: hashed slices for every level, float-atomic flush
   const uint32_t stripes = (N + 1023u) / 1024u;
-  if (!reuse_coords)  // coordinates in scatter order + one bounding box per stripe
-    hipLaunchKernelGGL(normalise_kernel, dim3(stripes), dim3(1024), 0, st, ps, N, g, (float*)(wsb + w.xnorm), (float*)(wsb + w.bounds_part));
+  const bool clears = !reuse_coords && full && w.dense_levels > 0;  // launch_lds' dl: dense levels only with the full workspace
+  if (!reuse_coords)  // coordinates in scatter order + one bounding box per stripe (+ the dense levels' row tables cleared)
+    hipLaunchKernelGGL(normalise_kernel, dim3(stripes), dim3(1024), 0, st, ps, N, g, (float*)(wsb + w.xnorm), (float*)(wsb + w.bounds_part),
+                       (uint4*)(wsb + w.g64), clears ? (size_t)w.dense_levels * (size_t)g.T : (size_t)0);
   uint32_t* abs_part = (uint32_t*)(wsb + w.abs_part);
   int abs_blocks = 0;
   if (!dy_absmax) {
@@ -869,7 +874,7 @@ extern "C" int hbr_hash_encode_bwd(const float* x, const float* rays_o, const fl
   }
   hipLaunchKernelGGL(meta_reduce_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)abs_part, abs_blocks, dy_absmax,
                      (const float*)(wsb + w.bounds_part), stripes, L, (Meta*)(wsb + w.meta));
-#define HBR_BWD(P, LY, DT) rc = launch_lds<P, LY, DT>(st, N, dy, dy_stride, g, dtables, wsb, w, full, overwrite)
+#define HBR_BWD(P, LY, DT) rc = launch_lds<P, LY, DT>(st, N, dy, dy_stride, g, dtables, wsb, w, full, overwrite, clears)
   if (g.pow2) {
     if (layout == HBR_LAYOUT_PLANAR) { if (dy_dtype == HBR_F32) HBR_BWD(true, HBR_LAYOUT_PLANAR, HBR_F32); else HBR_BWD(true, HBR_LAYOUT_PLANAR, HBR_BF16); }
     else { if (dy_dtype == HBR_F32) HBR_BWD(true, HBR_LAYOUT_ROWS, HBR_F32); else HBR_BWD(true, HBR_LAYOUT_ROWS, HBR_BF16); }
