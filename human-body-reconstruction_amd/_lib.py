@@ -15,6 +15,7 @@ IMAGE_READY = 0x100  # hbr_hip.h: OR-ed into hbr_mlp_bwd's precision
 OVERWRITE = 0x200    # hbr_hip.h: OR-ed into hbr_hash_encode_bwd's algo / hbr_mlp_bwd's precision
 EUNSUPPORTED = -2
 MLP_PARAM_FLOATS = 14227
+VERSION = 300           # HBR_VERSION of include/hbr_hip.h this binding was written against
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 

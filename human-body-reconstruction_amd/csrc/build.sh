@@ -4,7 +4,7 @@ set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
 OUT="$HERE/../libhbr_hip.so"
-FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wno-unused-value -I"$ROOT/include" -I"$HERE")
+FLAGS=(--offload-arch=gfx950 -fvisibility=hidden -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wno-unused-value -I"$ROOT/include" -I"$HERE")
 mkdir -p "$HERE/build"
 pids=()
 for f in c_api sample render hash_encode hash_scatter composite optim mlp; do
@@ -18,5 +18,5 @@ for f in c_api sample render hash_encode hash_scatter composite optim mlp; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE"/build/{c_api,sample,render,hash_encode,hash_scatter,composite,optim,mlp}.o
+hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script="$HERE/exports.map" -o "$OUT" "$HERE"/build/{c_api,sample,render,hash_encode,hash_scatter,composite,optim,mlp}.o
 echo "built $OUT"

@@ -24,6 +24,7 @@
 //     level, each keeping the corners that fall into its slice.  The x term of the hash is the cell coordinate
 //     itself, so the two x-neighbours of a (y, z) pair are always in the slice together: four tests, not eight.
 //   Chunk partials leave the workgroups as plain stores and are summed in a fixed order (slab_reduce_kernel).
+#include <mutex>
 #include <type_traits>
 
 #include "hash_common.h"
@@ -800,6 +801,39 @@ static int launch_lds(hipStream_t st, uint32_t N, const void* dy, int64_t stride
 
 static bool lds_shape_ok(int64_t N, int L, int64_t T) { return N >= 1 && L >= 1 && T >= 1 && T <= kMaxLdsT; }
 
+// algo 3's contract, made checkable: what the last algo-2 call that FILLED a workspace's coordinate block normalised
+// (point source, shape, mu / sigma) and on which stream.  The record lives on the host, keyed by the workspace pointer
+// (a handful of workspaces at most: one per stream in a training process); algo 3 is refused unless it names the same
+// points on the same stream - so a second caller that ran hbr_hash_encode_bwd on the same workspace between the two
+// halves is detected instead of silently scattering the first caller's gradients to the second caller's cells.
+struct CoordToken {
+  const void* ws;
+  const void *x, *o, *d, *t;
+  int64_t R, S;
+  float mu[3], sigma;
+  void* stream;
+};
+static std::mutex g_token_mutex;
+static CoordToken g_tokens[16];
+static int g_token_next = 0;
+static bool token_equal(const CoordToken& a, const CoordToken& b) {
+  return a.ws == b.ws && a.x == b.x && a.o == b.o && a.d == b.d && a.t == b.t && a.R == b.R && a.S == b.S &&
+         a.mu[0] == b.mu[0] && a.mu[1] == b.mu[1] && a.mu[2] == b.mu[2] && a.sigma == b.sigma && a.stream == b.stream;
+}
+static void token_record(const CoordToken& tk) {
+  std::lock_guard<std::mutex> lock(g_token_mutex);
+  for (auto& e : g_tokens)
+    if (e.ws == tk.ws) { e = tk; return; }
+  g_tokens[g_token_next] = tk;
+  g_token_next = (g_token_next + 1) % 16;
+}
+static bool token_matches(const CoordToken& tk) {
+  std::lock_guard<std::mutex> lock(g_token_mutex);
+  for (auto& e : g_tokens)
+    if (e.ws == tk.ws) return token_equal(e, tk);
+  return false;
+}
+
 }  // namespace hbr
 
 using namespace hbr;
@@ -855,6 +889,12 @@ extern "C" int hbr_hash_encode_bwd(const float* x, const float* rays_o, const fl
     return HBR_OK;
   }
   char* wsb = (char*)ws;
+  const CoordToken token{ws, x, rays_o, rays_d, t, R, S, {g.mu[0], g.mu[1], g.mu[2]}, g.sigma, stream};
+  if (reuse_coords) {
+    if (!token_matches(token)) return HBR_EINVAL;  // not the points the last algo-2 call left in this workspace
+  } else {
+    token_record(token);
+  }
   const bool full = ws_bytes >= w.total;  // else: hashed slices for every level, float-atomic flush
   const uint32_t stripes = (N + 1023u) / 1024u;
   const bool clears = !reuse_coords && full && w.dense_levels > 0;  // launch_lds' dl: dense levels only with the full workspace

@@ -31,16 +31,25 @@ def get_od(H, W, K, c2w: torch.Tensor, find_inv: Optional[bool] = False):
     return o, d / n, n
 
 
-_strat_draws = 0  # draws taken from the device-side generator since import (the counter of the counter-based RNG)
+def _take_cuda_philox(device, n: int):
+    """(seed, offset) of the device's torch CUDA generator, advancing it by n draws - what a torch.rand(n) on that
+    device would consume (Philox offsets move in units of 4).  So `torch.manual_seed(s)` replays the same depths,
+    `torch.cuda.get_rng_state` / `set_rng_state` save and restore them, and nothing process-global is kept here."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    gen = torch.cuda.default_generators[idx]
+    seed, off = gen.initial_seed(), gen.get_offset()
+    gen.set_offset(off + (int(n) + 3) // 4 * 4)
+    return seed, off
 
 
 def strat_sampler(tn, tf, num_samples: int, exp: Optional[bool] = False, device=None) -> torch.Tensor:
     """t[S] = linspace(tn,tf,S) + U[0,1)^S * (tf-tn)/S  (helper.py:210-237); ONE jitter per sample index,
     shared by every ray; may exceed tf.  `exp` samples uniformly in log-depth.
-    On the GPU (non-exp) this is one kernel launch: the uniforms come from a counter-based generator keyed by torch's
-    CUDA seed (`torch.manual_seed` makes runs repeat) and a per-process draw counter.  On the CPU, and for `exp`, the
-    reference's torch ops are used as they are."""
-    global _strat_draws
+    On the GPU (non-exp) this is one kernel launch: the uniforms come from a counter-based generator keyed by the
+    (seed, offset) of torch's CUDA generator for that device, which is advanced as torch.rand would advance it - the
+    values differ from torch.rand's, the reproducibility rules do not.  On the CPU, and for `exp`, the reference's torch
+    ops are used as they are."""
     if device is None:
         device = "cuda" if torch.cuda.is_available() else "cpu"
     tn, tf = torch.as_tensor(tn, dtype=torch.float32), torch.as_tensor(tf, dtype=torch.float32)
@@ -49,8 +58,8 @@ def strat_sampler(tn, tf, num_samples: int, exp: Optional[bool] = False, device=
         lt = lt + torch.rand_like(lt) * float(torch.log(tf) - torch.log(tn)) / num_samples
         return torch.exp(lt)
     if torch.device(device).type == "cuda":
-        _strat_draws += 1
-        return ops.strat_sample(float(tn), float(tf), int(num_samples), device, seed=torch.cuda.initial_seed(), offset=_strat_draws)
+        seed, off = _take_cuda_philox(device, num_samples)
+        return ops.strat_sample(float(tn), float(tf), int(num_samples), device, seed=seed, offset=off)
     t = torch.linspace(float(tn), float(tf), num_samples, device=device)
     return t + torch.rand_like(t) * float(tf - tn) / num_samples
 

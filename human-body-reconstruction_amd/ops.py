@@ -15,7 +15,19 @@ from . import _lib
 from ._lib import BF16, EUNSUPPORTED, F32, IMAGE_READY, OVERWRITE, PLANAR, ROWS, HbrError, check, lib, require_gpu
 
 _ws_cache = {}
-_MAX_SCATTER_WS = 8 << 30  # largest K2 workspace allocated for the reproducible (slab) flush
+_MAX_SCATTER_WS = 1 << 30  # largest K2 workspace allocated for the reproducible (slab) flush; beyond: the minimal one
+
+
+def free_workspaces(device=None) -> int:
+    """Drop the cached scratch buffers (all, or one device's); returns the bytes released to torch's allocator.  The
+    buffers are keyed by (kind, device, stream) and otherwise live as long as the process; nothing in them outlives a
+    call, except the coordinates an `algo=3` hash_encode_bwd re-uses - do not call this between those two calls."""
+    dev = None if device is None else torch.device(device)
+    n = 0
+    for key in list(_ws_cache):
+        if dev is None or torch.device(key[1]) == dev:
+            n += _ws_cache.pop(key).numel()
+    return n
 
 
 def _stream() -> int:
@@ -34,10 +46,13 @@ def _elem_dtype(t: torch.Tensor, what: str) -> int:
 
 def _workspace(kind, nbytes: int, device) -> torch.Tensor:
     """Scratch buffers are keyed by (kind, device, STREAM): kernels of one stream run in order, so a buffer may be
-    reused by the next call on that stream, while two streams never share one.  Grows, never shrinks."""
+    reused by the next call on that stream, while two streams never share one."""
     key = (kind, device, _stream())
     ws = _ws_cache.get(key)
-    if ws is None or ws.numel() < nbytes:
+    if ws is None or ws.numel() < nbytes or ws.numel() > 4 * nbytes + (64 << 20):
+        # grow on demand; give a buffer back once a request needs less than a quarter of it (one large call does not
+        # pin its scratch for the rest of the process)
+        _ws_cache.pop(key, None)
         ws = torch.empty(nbytes + 64, dtype=torch.uint8, device=device)
         _ws_cache[key] = ws
     return ws

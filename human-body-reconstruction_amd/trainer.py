@@ -21,7 +21,7 @@ from typing import Optional
 
 import torch
 
-from . import ops
+from . import _lib, ops
 from .dist import StagedAllReduce
 from ._lib import BF16, F32, MLP_PARAM_FLOATS, PLANAR
 from .encoder import PositionalEncoder
@@ -141,7 +141,11 @@ class HashNeRFTrainer:
             red.launch(self.grad[nt:])
 
             def scatter_halves():  # timed as ONE hash_bwd span (both launches), like the single-launch path
-                lds = self.scatter_algo in (0, 2) and R * S >= 65536  # the second half re-uses the first half's coordinates
+                # the second half re-uses the first half's coordinates (algo 2 then 3) - where the LDS kernels can run at
+                # all: for a shape they refuse (T > 2^28: workspace size 0) both halves take the caller's algo, so a
+                # model that trains on one GPU does not raise on N
+                lds = (self.scatter_algo in (0, 2) and R * S >= 65536
+                       and _lib.lib().hbr_hash_bwd_workspace_bytes(R * S, half, g.T, g.F, 2) > 0)
                 for k, (lo, hi, piece) in enumerate(((half, g.L, self.grad[cut:nt]), (0, half, self.grad[:cut]))):
                     sub = ops.HashGeom(g.scales[lo:hi], g.mu, g.sigma, g.T, g.F)
                     ops.hash_encode_bwd(sub, dfeat[lo:hi], self.g_tab[lo:hi], rays=rays, layout=PLANAR,

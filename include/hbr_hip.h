@@ -23,7 +23,10 @@
 extern "C" {
 #endif
 
-#define HBR_VERSION 202 /* 0.2.2: HBR_IMAGE_READY, HBR_OVERWRITE */
+/* The library is built with -fvisibility=hidden: only the entry points declared here are exported. */
+#define HBR_API __attribute__((visibility("default")))
+
+#define HBR_VERSION 300 /* 0.3.0: checked algo-3 contract, hidden visibility */
 
 enum {
   HBR_OK = 0,
@@ -53,10 +56,10 @@ enum { HBR_IMAGE_READY = 0x100 };
  * the caller then zeroes the buffer and calls again without the flag. */
 enum { HBR_OVERWRITE = 0x200 };
 
-int hbr_version(void);
-const char* hbr_strerror(int code);
+HBR_API int hbr_version(void);
+HBR_API const char* hbr_strerror(int code);
 /* 1 if a HIP device with gcnArchName gfx950 is visible, 0 otherwise */
-int hbr_device_ok(void);
+HBR_API int hbr_device_ok(void);
 
 /* ---- K0: sampling along rays ------------------------------------------------------------------
  * hbr_strat_sample replaces strat_sampler, helper.py:210-237 (non-exp branch):
@@ -69,9 +72,9 @@ int hbr_device_ok(void);
  *   grid DEVICE [G,G,G] bytes (a torch.bool tensor), read live; keep DEVICE [N] bytes out.
  *   A negative index counts from the end (torch indexing); outside [-G, G) - where torch raises - is "not kept".
  */
-int hbr_strat_sample(float tn, float tf, int64_t S, const float* u, uint64_t seed, uint64_t offset, float* t,
+HBR_API int hbr_strat_sample(float tn, float tf, int64_t S, const float* u, uint64_t seed, uint64_t offset, float* t,
                      void* stream);
-int hbr_occupancy_mask(const float* x, const float* rays_o, const float* rays_d, const float* t, int64_t R,
+HBR_API int hbr_occupancy_mask(const float* x, const float* rays_o, const float* rays_d, const float* t, int64_t R,
                        int64_t S, const uint8_t* grid, int G, const float* mu_host, float sigma_val,
                        uint8_t* keep, void* stream);
 
@@ -89,7 +92,7 @@ int hbr_occupancy_mask(const float* x, const float* rays_o, const float* rays_d,
  *   y        output, layout per `layout`; row stride `y_stride` elements for HBR_LAYOUT_ROWS
  *            (>= L*F; extra columns are left untouched -- the reference's E aux columns)
  */
-int hbr_hash_encode_fwd(const float* x, const float* rays_o, const float* rays_d, const float* t,
+HBR_API int hbr_hash_encode_fwd(const float* x, const float* rays_o, const float* rays_d, const float* t,
                         int64_t R, int64_t S, const float* tables, const float* scales_host,
                         const float* mu_host, float sigma, int L, int64_t T, int F, void* y,
                         int layout, int64_t y_stride, int y_dtype, void* stream);
@@ -106,23 +109,27 @@ int hbr_hash_encode_fwd(const float* x, const float* rays_o, const float* rays_d
  *                With the full workspace the chunk partials are reduced in a fixed order and the result of a launch
  *                is bitwise reproducible; with only the first hbr_hash_bwd_workspace_bytes_min() bytes they are
  *                added with float atomics (same values up to the order of <= chunks fp32 additions per entry).
- *            3 = 2, re-using the normalised coordinates the PREVIOUS algo-2/3 call left in `ws`: same points, same
- *                mu/sigma, same `ws` (a launch over another range of levels - the multi-GPU trainer scatters the levels
- *                in two calls so that each half's all-reduce overlaps the other half's kernel)
+ *            3 = 2, re-using the normalised coordinates the PREVIOUS algo-2 call left in `ws` (a launch over another
+ *                range of levels - the multi-GPU trainer scatters the levels in two calls so that each half's
+ *                all-reduce overlaps the other half's kernel).  The contract is CHECKED: the library records, per `ws`
+ *                pointer, which points the last algo-2 call normalised into it (x / rays_o / rays_d / t pointers, R, S,
+ *                mu, sigma) and on which stream; algo 3 returns HBR_EINVAL unless this call names exactly those - e.g.
+ *                when another caller ran an algo-2 backward on the same workspace in between.  (What it cannot see: a
+ *                kernel of another stream overwriting `ws`; a workspace belongs to one stream.)
  *            0 = auto: 2 when N >= 65536, T <= 2^28 and the workspace suffices, else 1
  *   ws       16-byte-aligned scratch of hbr_hash_bwd_workspace_bytes() bytes (normalised coordinates, per-level
  *            maxima, per-chunk partial tables); contents are dead after the call
  *   errors   algo 2 without enough workspace -> HBR_EWORKSPACE; algo 2 with T > 2^28 -> HBR_EUNSUPPORTED
  */
-int hbr_hash_encode_bwd(const float* x, const float* rays_o, const float* rays_d, const float* t,
+HBR_API int hbr_hash_encode_bwd(const float* x, const float* rays_o, const float* rays_d, const float* t,
                         int64_t R, int64_t S, const void* dy, int layout, int64_t dy_stride,
                         int dy_dtype, const float* dy_absmax, const float* scales_host,
                         const float* mu_host, float sigma, int L, int64_t T, int F, float* dtables,
                         int algo, void* ws, int64_t ws_bytes, void* stream);
 /* full workspace of algo 2 for this shape (0 when `algo`/N/T select the global-atomics kernel) */
-int64_t hbr_hash_bwd_workspace_bytes(int64_t N, int L, int64_t T, int F, int algo);
+HBR_API int64_t hbr_hash_bwd_workspace_bytes(int64_t N, int L, int64_t T, int F, int algo);
 /* the part of it algo 2 cannot run without (coordinates + maxima, 12 B per point) */
-int64_t hbr_hash_bwd_workspace_bytes_min(int64_t N, int L, int64_t T, int F, int algo);
+HBR_API int64_t hbr_hash_bwd_workspace_bytes_min(int64_t N, int L, int64_t T, int F, int algo);
 
 /* ---- K5: alpha compositing along rays ---------------------------------------------------------
  * Replaces calc_color, helper.py:53-107 (non-SDF branch).
@@ -132,13 +139,13 @@ int64_t hbr_hash_bwd_workspace_bytes_min(int64_t N, int L, int64_t T, int F, int
  *         pass rgb = out, sigma = out+3 and elem strides rgb_stride = sigma_stride = 4
  *   Cr [R,3]; wts [R,S] (may be NULL)
  */
-int hbr_composite_fwd(const float* t, int64_t t_stride, const float* rgb, int64_t rgb_stride, const float* sigma,
+HBR_API int hbr_composite_fwd(const float* t, int64_t t_stride, const float* rgb, int64_t rgb_stride, const float* sigma,
                       int64_t sigma_stride, const float* dir_norm, int64_t R, int64_t S, float* Cr,
                       float* wts, void* stream);
 /* d_rgb / d_sigma use the same strides as their forward counterparts.
  * keep: optional DEVICE [R*S] bytes (hbr_occupancy_mask): gradients of samples with keep == 0 are written as 0
  * (vol_renderer.py:209-221: their sigma/rgb are zeros, not model outputs) */
-int hbr_composite_bwd(const float* t, int64_t t_stride, const float* rgb, int64_t rgb_stride, const float* sigma,
+HBR_API int hbr_composite_bwd(const float* t, int64_t t_stride, const float* rgb, int64_t rgb_stride, const float* sigma,
                       int64_t sigma_stride, const float* dir_norm, int64_t R, int64_t S,
                       const float* dCr, float* d_rgb, float* d_sigma, const uint8_t* keep, void* stream);
 
@@ -146,7 +153,7 @@ int hbr_composite_bwd(const float* t, int64_t t_stride, const float* rgb, int64_
  * Replaces PositionalEncoder.forward, encoder.py:25-32: for each row and coordinate c,
  * out[row, c*2nf + k] = sin(2*x_c*k), out[row, c*2nf + nf + k] = cos(2*x_c*k), k = 0..nf-1.
  *   x [rows, d_model] fp32 -> out [rows, d_model*2*num_freq] fp32 */
-int hbr_dir_encode(const float* x, int64_t rows, int d_model, int num_freq, float* out, void* stream);
+HBR_API int hbr_dir_encode(const float* x, int64_t rows, int d_model, int num_freq, float* out, void* stream);
 
 /* ---- K3/K4: fused density/colour MLP on the matrix cores --------------------------------------
  * Replaces MLP_3D.forward (test_hash.py:52-72) for the instance built at train_hash2.py:127
@@ -166,8 +173,8 @@ int hbr_dir_encode(const float* x, int64_t rows, int d_model, int num_freq, floa
  *            reduced within one hbr_mlp_bwd call)
  */
 enum { HBR_MLP_PARAM_FLOATS = 14227 };
-int64_t hbr_mlp_workspace_bytes(int precision);
-int hbr_mlp_fwd(const void* feat, int layout, int64_t feat_stride, int feat_dtype,
+HBR_API int64_t hbr_mlp_workspace_bytes(int precision);
+HBR_API int hbr_mlp_fwd(const void* feat, int layout, int64_t feat_stride, int feat_dtype,
                 const float* viewdirs_enc, int64_t N, int64_t group, const float* params,
                 int precision, float* out, const uint8_t* keep, void* ws, int64_t ws_bytes, void* stream);
 /* backward: recomputes the forward activations from `feat`, then
@@ -177,7 +184,7 @@ int hbr_mlp_fwd(const void* feat, int layout, int64_t feat_stride, int feat_dtyp
  *            dy_absmax - saves that call its own pass over dfeat; NULL or dfeat == NULL => not produced
  *   dparams  [14227] fp32, ACCUMULATED INTO (fixed summation order: bitwise reproducible)
  */
-int hbr_mlp_bwd(const void* feat, int layout, int64_t feat_stride, int feat_dtype,
+HBR_API int hbr_mlp_bwd(const void* feat, int layout, int64_t feat_stride, int feat_dtype,
                 const float* viewdirs_enc, int64_t N, int64_t group, const float* params,
                 int precision, const float* dout, void* dfeat, float* dfeat_absmax, float* dparams,
                 void* ws, int64_t ws_bytes, void* stream);
@@ -190,8 +197,8 @@ int hbr_mlp_bwd(const void* feat, int layout, int64_t feat_stride, int feat_dtyp
  *   Cr [R,3] out;  wts [R,S] out or NULL;  out [R*S,4] (r,g,b,sigma) out, or NULL to keep it inside the workspace
  *   ws     256-byte-aligned scratch of hbr_render_fwd_workspace_bytes(R, S, L, precision, feat_dtype, out == NULL)
  */
-int64_t hbr_render_fwd_workspace_bytes(int64_t R, int64_t S, int L, int precision, int feat_dtype, int own_out);
-int hbr_render_fwd(const float* rays_o, const float* rays_d, const float* t, const float* dir_norm, int64_t R,
+HBR_API int64_t hbr_render_fwd_workspace_bytes(int64_t R, int64_t S, int L, int precision, int feat_dtype, int own_out);
+HBR_API int hbr_render_fwd(const float* rays_o, const float* rays_d, const float* t, const float* dir_norm, int64_t R,
                    int64_t S, const float* tables, const float* scales_host, const float* mu_host, float sigma,
                    int L, int64_t T, int F, const float* params, int precision, int feat_dtype,
                    const uint8_t* keep, float* Cr, float* wts, float* out, void* ws, int64_t ws_bytes,
@@ -203,8 +210,8 @@ int hbr_render_fwd(const float* rays_o, const float* rays_d, const float* t, con
  * ws: optional scratch of hbr_mse2_workspace_bytes() bytes whose LAST 4 bytes are zero on first use (the kernel
  *     leaves them zero): block sums are then added in a fixed order and the loss is bitwise reproducible.
  *     NULL => one float atomic per block.  */
-int64_t hbr_mse2_workspace_bytes(void);
-int hbr_mse2_loss_fwd_bwd(const float* Cr, const float* gt, int64_t R, float gscale, float* loss_out,
+HBR_API int64_t hbr_mse2_workspace_bytes(void);
+HBR_API int hbr_mse2_loss_fwd_bwd(const float* Cr, const float* gt, int64_t R, float gscale, float* loss_out,
                           float* dCr, void* ws, void* stream);
 
 /* ---- a12: dense Adam / AdamW over a flat fp32 buffer -----------------------------------------
@@ -212,7 +219,7 @@ int hbr_mse2_loss_fwd_bwd(const float* Cr, const float* gt, int64_t R, float gsc
  * p *= 1-lr*wd (AdamW; wd = 0 for Adam), m,v EMA, bias correction with `step` (1-based),
  * p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).  grad_scale multiplies g first (1/world_size after
  * the all-reduce). */
-int hbr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+HBR_API int hbr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
                   void* stream);
 

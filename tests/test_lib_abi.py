@@ -27,7 +27,13 @@ def test_header_symbols_all_exported(L):
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in hbr_hip.h but not exported by libhbr_hip.so"
     assert declared == set(L.SIGNATURES), (declared ^ set(L.SIGNATURES))
-    assert lib.hbr_version() == 202
+    # ... and nothing else: the library is linked with -fvisibility=hidden + a version script (no kernel stubs, no
+    # C++ helpers, no __hip_cuid_* in the dynamic symbol table)
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if ln.strip()}
+    assert exported == declared, sorted(exported ^ declared)
+    assert lib.hbr_version() == L.VERSION
     assert lib.hbr_strerror(-2).decode().startswith("configuration not supported")
     # MFMA-fragment image of the weights (34 KiB forward + 28 KiB backward + 6 x 64 biases), then one weight-gradient
     # slab per backward workgroup: 256 workgroups x 4 waves x (6 tiles x 16 + 10 bias) registers x 64 lanes x 4 B
