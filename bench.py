@@ -89,6 +89,46 @@ def cpu_baseline(S, mn, sig, total_steps, Rc=4096, budget_s=25.0):
     return out
 
 
+def dropin_leg(dev, batches, mn, sig, S, steps, warmup, total_steps, precision):
+    """The boundary BASELINE.json's north_star names: the loop body of /root/reference/train_hash2.py:211-234 written
+    against the drop-in classes - Volume_Renderer.vol_render under autocast, MSE(Cr)+MSE(Cf), loss.backward(),
+    torch.optim.Adam(lr .05) on encoder.Embedding_list / AdamW(lr .005) on DataParallel(MLP_3D), two
+    CosineAnnealingLR, zero_grad(set_to_none=True) - on the same resident 16 000-ray batches as the fused step.
+    (bf16 autocast needs no GradScaler; the reference's scaler is an fp16 device.)  Returns ms per step."""
+    import torch
+    from hbr_amd.trainer import build_default_model
+    from hbr_amd.vol_renderer import Volume_Renderer
+    enc, denc, mlp = build_default_model(mn, sig, dev, seed=0)                                  # train_hash2.py:120-127
+    nerf = torch.nn.DataParallel(mlp, device_ids=[dev.index])
+    vr = Volume_Renderer(H=800, W=800, K=torch.eye(3), near=2.0, far=6.0, device=dev, Pos_encode=enc, Dir_encode=denc,
+                         max_dim=2 ** 10, sigma_val=sig.to(dev), mu=mn.to(dev))                  # :124-126
+    oe = torch.optim.Adam(enc.Embedding_list.parameters(), lr=0.05)                             # :141
+    om = torch.optim.AdamW(nerf.parameters(), lr=0.005)                                         # :142
+    se = torch.optim.lr_scheduler.CosineAnnealingLR(oe, T_max=total_steps, eta_min=1e-4)        # :156-159
+    sm = torch.optim.lr_scheduler.CosineAnnealingLR(om, T_max=total_steps, eta_min=1e-4)        # :160-162
+    crit = torch.nn.MSELoss()                                                                   # :177
+
+    def step(i):
+        o, d, dn, gt = batches[i % len(batches)]
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=precision == "bf16"):         # :218
+            Cr, Cf, _ = vr.vol_render(nerf, d, o, num_samples=S, update_mask=False, dir_norm=dn, hierarchical=False)  # :220
+            loss = crit(Cr, gt) + crit(Cf, gt)                                                  # :221
+        loss.backward()                                                                         # :226
+        oe.step(); om.step()                                                                    # :227-228
+        se.step(); sm.step()                                                                    # :231-232
+        om.zero_grad(set_to_none=True); oe.zero_grad(set_to_none=True)                          # :233-234
+        return loss
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = step(i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3, float(loss.detach())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,6 +143,8 @@ def main():
                     help="weak: --rays per rank; strong: --rays in total, split over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the reference-loop-on-drop-in-classes leg (N=1 only)")
+    ap.add_argument("--only-dropin", action="store_true", help="profiling aid: run only the drop-in leg and print its ms/step")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -167,6 +209,10 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    if args.only_dropin:
+        ms, dl = dropin_leg(dev, batches, mn, sig, S, args.steps, args.warmup, total_steps, args.precision)
+        print(json.dumps({"dropin_ms_per_step": ms, "dropin_value": R * S / (ms * 1e-3), "loss": dl, "steps": args.steps}), flush=True)
+        return
     print(f"[bench] rank {rank}/{world}: model + {pool} batches resident, warming up", file=sys.stderr, flush=True)
     for i in range(args.warmup):
         tr.step(*batches[i % pool])
@@ -213,6 +259,13 @@ def main():
             r["traffic"] = pmc.get(k)  # HBM bytes per launch from rocprofv3 --pmc passes (profiles/), or null
     dominant = max(kern, key=kern.get) if kern else None
 
+    # ---- the reference's own loop on the drop-in classes (the boundary north_star names), same batches ---------
+    dropin = None
+    if rank == 0 and world == 1 and not args.no_dropin:
+        ms, dl = dropin_leg(dev, batches, mn, sig, S, args.steps, args.warmup, total_steps, args.precision)
+        dropin = dict(ms_per_step=ms, value=R * S / (ms * 1e-3), loss=dl)
+        print(f"[bench] drop-in loop: {ms:.3f} ms/step", file=sys.stderr, flush=True)
+
     # ---- CPU baseline: the oracle (a port of the reference's PyTorch-CPU path) on a bounded sample ---------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -233,6 +286,8 @@ def main():
             "loss": loss,
             "roofline": roofs.get(dominant), "roofline_hash_lookup": roofs.get("hash_fwd"), "kernels": roofs or None,
             "cpu_baseline": cpu,
+            # train_hash2.py:211-234 as written (vol_render + autograd + torch.optim), drop-in classes, same batches
+            "dropin_ms_per_step": dropin and dropin["ms_per_step"], "dropin_value": dropin and dropin["value"],
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -41,7 +41,17 @@ SIGNATURES = {
     "hbr_mse2_workspace_bytes": (_l, []),
     "hbr_mse2_loss_fwd_bwd": (_i, [_p, _p, _l, _f, _p, _p, _p, _p]),
     "hbr_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _l, _f, _p]),
+    "hbr_adam_step_multi": (_i, [_i, _p, _p]),
+    "hbr_render_prologue": (_i, [_f, _f, _l, _p, C.c_uint64, C.c_uint64, _p, _p, _l, _p, _p, _i, _p, _l, _p]),
+    "hbr_composite_loss_workspace_bytes": (_l, [_l]),
+    "hbr_composite_loss_fwd_bwd": (_i, [_p, _l, _p, _l, _p, _l, _p, _l, _l, _p, _f, _p, _p, _p, _p, _p, _p, _p]),
 }
+
+
+class AdamSegment(C.Structure):
+    """HbrAdamSegment of include/hbr_hip.h"""
+    _fields_ = [("p", _p), ("g", _p), ("m", _p), ("v", _p), ("n", _l), ("lr", _f), ("beta1", _f), ("beta2", _f), ("eps", _f),
+                ("weight_decay", _f), ("step", _l), ("grad_scale", _f)]
 
 _lib = None
 

@@ -23,6 +23,7 @@
 // One wave per SIMD in the backward kernel: everything below that looks like scheduling by hand (requests ahead of a
 // fence, MFMAs pinned between epilogue words, vectors built whole) is there because of it - DESIGN.md section 3.
 #include "hbr_common.h"
+#include "sample_common.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -192,10 +193,10 @@ struct Tab {
 
 // global image: [ALL_FRAGS][64 lanes] fragments, then [6][64] padded biases
 template <class P>
-__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ params, char* __restrict__ img) {
+__device__ __forceinline__ void pack_body(const float* __restrict__ params, char* __restrict__ img, int block, int nblocks) {
   using T = Tab<P>;
   const int total = T::ALL_FRAGS * 64;
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < total + NLAYER * 64; e += gridDim.x * 256) {
+  for (int e = block * 256 + threadIdx.x; e < total + NLAYER * 64; e += nblocks * 256) {
     if (e >= total) {  // biases
       const int b = e - total, l = b / 64, row = b % 64;
       const int off = blog_offset(l, row);
@@ -242,6 +243,10 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ par
     }
     ((typename P::frag*)img)[e] = f;
   }
+}
+template <class P>
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ params, char* __restrict__ img) {
+  pack_body<P>(params, img, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1386,10 +1391,10 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
 // ------------------------------------------------------------------------------------------------
 // view-direction encoding (a7): out[row, c*2nf + k] = sin(2*x_c*k), out[row, c*2nf + nf + k] = cos(2*x_c*k)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dir_encode_kernel(const float* __restrict__ x, int64_t rows, int d, int nf,
-                                                         float* __restrict__ out) {
+__device__ __forceinline__ void dir_encode_body(const float* __restrict__ x, int64_t rows, int d, int nf, float* __restrict__ out,
+                                                int64_t block, int64_t nblocks) {
   const int64_t total = rows * d * nf;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+  for (int64_t e = block * 256 + threadIdx.x; e < total; e += nblocks * 256) {
     const int k = (int)(e % nf);
     const int64_t rc = e / nf;
     const int c = (int)(rc % d);
@@ -1399,6 +1404,29 @@ __global__ __launch_bounds__(256) void dir_encode_kernel(const float* __restrict
     o[k] = sinf(ang);
     o[nf + k] = cosf(ang);
   }
+}
+__global__ __launch_bounds__(256) void dir_encode_kernel(const float* __restrict__ x, int64_t rows, int d, int nf,
+                                                         float* __restrict__ out) {
+  dir_encode_body(x, rows, d, nf, out, (int64_t)blockIdx.x, (int64_t)gridDim.x);
+}
+
+// What a render call does before the encoder runs, in ONE launch (three ~4.5 us launches otherwise): the weight-fragment
+// image (blocks [0, pack_blocks)), the per-ray direction encoding (the next dir_blocks) and the depths t[S] (the rest).
+template <class P>
+__global__ __launch_bounds__(256) void prologue_kernel(StratArgs sa, const float* __restrict__ dirs, int64_t rows, float* __restrict__ pe,
+                                                       const float* __restrict__ params, char* __restrict__ img, int pack_blocks,
+                                                       int dir_blocks) {
+  int b = (int)blockIdx.x;
+  if (b < pack_blocks) {
+    pack_body<P>(params, img, b, pack_blocks);
+    return;
+  }
+  b -= pack_blocks;
+  if (b < dir_blocks) {
+    dir_encode_body(dirs, rows, 3, 4, pe, b, dir_blocks);
+    return;
+  }
+  strat_sample_one(sa, (uint32_t)(b - dir_blocks) * 256u + threadIdx.x);
 }
 
 template <class P>
@@ -1505,9 +1533,38 @@ extern "C" int hbr_dir_encode(const float* x, int64_t rows, int d_model, int num
   return HBR_OK;
 }
 
+extern "C" int hbr_render_prologue(float tn, float tf, int64_t S, const float* u, uint64_t seed, uint64_t offset, float* t,
+                                   const float* rays_d, int64_t R, float* pe, const float* params, int precision, void* ws,
+                                   int64_t ws_bytes, void* stream) {
+  if (S < 0 || R < 0 || S > 0x7fffffffLL) return HBR_EINVAL;
+  if ((pe != nullptr) != (rays_d != nullptr)) return HBR_EINVAL;
+  if (params) {
+    if (precision != HBR_F32 && precision != HBR_BF16) return HBR_EINVAL;
+    if (!ws || ((uintptr_t)ws & 15)) return HBR_EINVAL;
+    if (ws_bytes < hbr_mlp_workspace_bytes(precision)) return HBR_EWORKSPACE;
+  }
+  const int pack_blocks = params ? 64 : 0;
+  int64_t dir_blocks = (pe && R > 0) ? (R * 12 + 255) / 256 : 0;
+  if (dir_blocks > 4096) dir_blocks = 4096;
+  const int64_t strat_blocks = (t && S > 0) ? (S + 255) / 256 : 0;
+  const int64_t blocks = pack_blocks + dir_blocks + strat_blocks;
+  if (blocks == 0) return HBR_OK;
+  if (blocks > 0x7fffffffLL) return HBR_EUNSUPPORTED;
+  const StratArgs sa{tn, tf, (uint32_t)(t ? S : 0), u, seed, offset, t};
+  hipStream_t st = (hipStream_t)stream;
+  if (precision == HBR_BF16)
+    hipLaunchKernelGGL((prologue_kernel<PBf16>), dim3((uint32_t)blocks), dim3(256), 0, st, sa, rays_d, R, pe, params, (char*)ws, pack_blocks, (int)dir_blocks);
+  else
+    hipLaunchKernelGGL((prologue_kernel<PF32>), dim3((uint32_t)blocks), dim3(256), 0, st, sa, rays_d, R, pe, params, (char*)ws, pack_blocks, (int)dir_blocks);
+  HBR_RETURN_IF_LAUNCH_FAILED();
+  return HBR_OK;
+}
+
 extern "C" int hbr_mlp_fwd(const void* feat, int layout, int64_t feat_stride, int feat_dtype, const float* viewdirs_enc,
                            int64_t N, int64_t group, const float* params, int precision, float* out, const uint8_t* keep, void* ws,
                            int64_t ws_bytes, void* stream) {
+  const bool image_ready = (precision & HBR_IMAGE_READY) != 0;  // `ws` holds the image of THESE params (hbr_render_prologue)
+  precision &= ~HBR_IMAGE_READY;
   int rc = check_common(feat, layout, feat_stride, feat_dtype, viewdirs_enc, N, group, params, precision, ws, ws_bytes);
   if (rc) return rc;
   if (!out || ((uintptr_t)out & 15)) return HBR_EINVAL;
@@ -1520,11 +1577,11 @@ extern "C" int hbr_mlp_fwd(const void* feat, int layout, int64_t feat_stride, in
   if (blocks > 4096 / kFwdWaves) blocks = 4096 / kFwdWaves;
   char* img = (char*)ws;
   if (precision == HBR_BF16) {
-    pack<PBf16>(params, img, st);
+    if (!image_ready) pack<PBf16>(params, img, st);
     if (layout == HBR_LAYOUT_PLANAR) rc = launch_fwd<PBf16, HBR_LAYOUT_PLANAR>(feat_dtype, blocks, st, img, fs, ps, out, keep);
     else rc = launch_fwd<PBf16, HBR_LAYOUT_ROWS>(feat_dtype, blocks, st, img, fs, ps, out, keep);
   } else {
-    pack<PF32>(params, img, st);
+    if (!image_ready) pack<PF32>(params, img, st);
     if (layout == HBR_LAYOUT_PLANAR) rc = launch_fwd<PF32, HBR_LAYOUT_PLANAR>(feat_dtype, blocks, st, img, fs, ps, out, keep);
     else rc = launch_fwd<PF32, HBR_LAYOUT_ROWS>(feat_dtype, blocks, st, img, fs, ps, out, keep);
   }

@@ -16,7 +16,9 @@ def render_fine(renderer, mlp, rays_d, rays_o, t, wts, num_samples, dir_norm):
     stacked = enc.stacked_tables()
     flat, splits = mlp.flat_params()
     tabs = [lvl.weight for lvl in enc.Embedding_list]
-    Cf, _, _ = ops.RenderFn.apply(rays_o, rays_d, t_fine, dir_norm, enc.geometry(), stacked, flat, ops.precision_from_autocast(),
-                                  renderer.Dir_encode.max_seq_len, splits, renderer.feat_dtype, len(tabs), None, *tabs, *mlp._ordered())  # fine pass: no mask (vol_renderer.py:236)
+    prec = ops.precision_from_autocast()
+    Cf, _, _, _ = ops.RenderFn.apply(rays_o, rays_d, t_fine, dir_norm, enc.geometry(), stacked, flat, prec,
+                                  renderer.Dir_encode.max_seq_len, splits, prec if renderer.feat_dtype is None else renderer.feat_dtype,
+                                  len(tabs), None, *tabs, *mlp._ordered())  # fine pass: no mask (vol_renderer.py:236)
     renderer.last_t_fine = t_fine
     return Cf

@@ -72,6 +72,16 @@ def _mlp_ws(precision: int, device) -> torch.Tensor:
     return _workspace(("mlp", precision), lib().hbr_mlp_workspace_bytes(precision), device)
 
 
+# Which parameter block (storage + version) the weight-fragment image in an MLP workspace was last packed from, per
+# (device, stream, precision).  `mlp_bwd(image_ready=None)` skips the repack only when this says the image is current -
+# so a second model, or an optimiser step, between a forward and its backward costs a repack instead of wrong numbers.
+_mlp_image = {}
+
+
+def _image_key(params: torch.Tensor):
+    return (params.data_ptr(), params._version, params.numel())
+
+
 @dataclass(frozen=True)
 class HashGeom:
     """Host-side description of the grid: fp32 level scales (computed with the reference's torch ops),
@@ -204,32 +214,70 @@ def _feat_desc(feat: torch.Tensor, layout: int):
     return N, stride, dtype
 
 
+def render_prologue(device, precision: int, params: Optional[torch.Tensor] = None, rays_d: Optional[torch.Tensor] = None,
+                    strat: Optional[tuple] = None):
+    """One launch for what precedes the encoder in a render call: the depths t[S] (strat = (tn, tf, S, u or None, seed,
+    offset), as strat_sample), the direction encoding pe [R,24] of rays_d (num_freq 4) and the MLP's weight-fragment
+    image of `params` (a following mlp_fwd / mlp_bwd with image_ready=None finds it).  Each part is optional.
+    Returns (t or None, pe or None)."""
+    t = pe = u = None
+    tn = tf = 0.0
+    S = seed = off = R = 0
+    if strat is not None:
+        tn, tf, S, u, seed, off = strat
+        t = torch.empty(int(S), dtype=torch.float32, device=device)
+        if u is not None:
+            u = _f32c(u)
+            if u.numel() != S or not u.is_cuda:
+                raise HbrError("u must hold S floats on the device")
+    if rays_d is not None:
+        rays_d = _f32c(rays_d)
+        R = rays_d.shape[0]
+        pe = torch.empty((R, 24), dtype=torch.float32, device=device)
+    ws = _mlp_ws(precision, device) if params is not None else None
+    require_gpu(t if t is not None else (pe if pe is not None else ws))
+    check(lib().hbr_render_prologue(float(tn), float(tf), int(S), _ptr(u), int(seed) & (2 ** 64 - 1), int(off) & (2 ** 64 - 1), _ptr(t),
+                                    _ptr(rays_d) if R else None, R, _ptr(pe) if R else None, _ptr(params), precision, _ptr(ws),
+                                    ws.numel() if ws is not None else 0, _stream()), "hbr_render_prologue")
+    if params is not None:
+        _mlp_image[(torch.device(device), _stream(), precision)] = (ws.data_ptr(), _image_key(params))
+    return t, pe
+
+
 def mlp_fwd(feat: torch.Tensor, layout: int, viewdirs_enc: torch.Tensor, group: int, params: torch.Tensor, precision: int,
-            keep: Optional[torch.Tensor] = None):
-    """keep: optional [N] uint8/bool occupancy mask (occupancy_mask()); rows with keep == 0 come out as zeros."""
+            keep: Optional[torch.Tensor] = None, image_ready: Optional[bool] = False):
+    """keep: optional [N] uint8/bool occupancy mask (occupancy_mask()); rows with keep == 0 come out as zeros.
+    image_ready: as mlp_bwd's (None = this module's record of the last packing on this stream decides)."""
     require_gpu(feat)
     N, stride, dtype = _feat_desc(feat, layout)
     out = torch.empty((N, 4), dtype=torch.float32, device=feat.device)
     ws = _mlp_ws(precision, feat.device)
     if N == 0:
         return out
+    if image_ready is None:
+        image_ready = _mlp_image.get((feat.device, _stream(), precision)) == (ws.data_ptr(), _image_key(params))
     check(lib().hbr_mlp_fwd(feat.data_ptr(), layout, stride, dtype, viewdirs_enc.data_ptr(), N, group, params.data_ptr(),
-                            precision, out.data_ptr(), _ptr(keep), ws.data_ptr(), ws.numel(), _stream()), "hbr_mlp_fwd")
+                            precision | (IMAGE_READY if image_ready else 0), out.data_ptr(), _ptr(keep), ws.data_ptr(), ws.numel(), _stream()), "hbr_mlp_fwd")
+    _mlp_image[(feat.device, _stream(), precision)] = (ws.data_ptr(), _image_key(params))
     return out
 
 
 def mlp_bwd(feat: torch.Tensor, layout: int, viewdirs_enc: torch.Tensor, group: int, params: torch.Tensor, precision: int,
             dout: torch.Tensor, dparams: torch.Tensor, need_dfeat: bool = True, absmax_out: Optional[torch.Tensor] = None,
-            image_ready: bool = False, overwrite: bool = False):
+            image_ready: Optional[bool] = False, overwrite: bool = False):
     """absmax_out: optional [16] fp32 device tensor that receives max |d feat| per level (hash_encode_bwd's dy_absmax).
     image_ready: the last MLP call on this stream was `mlp_fwd` / `mlp_bwd` with the SAME params and precision (the
-    workspace still holds their fragment image) - skips the repack.  overwrite: dparams receives this call's gradient
+    workspace still holds their fragment image) - skips the repack; None = decide from this module's own record of
+    what was packed last (same storage, same version counter).  overwrite: dparams receives this call's gradient
     instead of accumulating it (no zeroing needed)."""
     N, stride, dtype = _feat_desc(feat, layout)
     # d feat takes feat's layout INCLUDING its row stride (the kernel addresses both with feat_stride): a strided rows
     # view such as y[:, :32] of an [N,36] buffer gets a gradient buffer with the same 36-element pitch
     dfeat = torch.empty_strided(feat.shape, feat.stride(), dtype=feat.dtype, device=feat.device) if need_dfeat else None
     ws = _mlp_ws(precision, feat.device)
+    ikey = (feat.device, _stream(), precision)
+    if image_ready is None:
+        image_ready = _mlp_image.get(ikey) == (ws.data_ptr(), _image_key(params))
     dout = _f32c(dout)
     if N == 0:
         if absmax_out is not None:
@@ -240,6 +288,7 @@ def mlp_bwd(feat: torch.Tensor, layout: int, viewdirs_enc: torch.Tensor, group: 
     check(lib().hbr_mlp_bwd(feat.data_ptr(), layout, stride, dtype, viewdirs_enc.data_ptr(), N, group, params.data_ptr(),
                             precision | (IMAGE_READY if image_ready else 0) | (OVERWRITE if overwrite else 0), dout.data_ptr(), _ptr(dfeat), _ptr(absmax_out), dparams.data_ptr(), ws.data_ptr(), ws.numel(),
                             _stream()), "hbr_mlp_bwd")
+    _mlp_image[ikey] = (ws.data_ptr(), _image_key(params))
     return dfeat
 
 
@@ -336,6 +385,33 @@ def mse2_loss(Cr: torch.Tensor, gt: torch.Tensor, gscale: float = 1.0, want_grad
     check(lib().hbr_mse2_loss_fwd_bwd(Cr.data_ptr(), gt.data_ptr(), Cr.shape[0], gscale, loss.data_ptr(), _ptr(dCr), ws.data_ptr(),
                                       _stream()), "hbr_mse2_loss_fwd_bwd")
     return loss, dCr
+
+
+def composite_loss_fwd_bwd(t, out: torch.Tensor, dir_norm, R: int, S: int, gt: torch.Tensor, gscale: float = 1.0,
+                           keep: Optional[torch.Tensor] = None, want_Cr: bool = False):
+    """composite_fwd + mse2_loss + composite_bwd on the MLP's [R*S,4] output in ONE launch (hierarchical off: Cf is Cr).
+    Returns (loss 0-d, d_out [R*S,4], Cr [R,3] or None)."""
+    require_gpu(out)
+    gt = _f32c(gt)
+    loss = torch.empty((), dtype=torch.float32, device=out.device)
+    d_out = torch.empty_like(out)
+    Cr = torch.empty((R, 3), dtype=torch.float32, device=out.device) if want_Cr else None
+    ws = _workspace("closs", lib().hbr_composite_loss_workspace_bytes(R), out.device)
+    check(lib().hbr_composite_loss_fwd_bwd(t.data_ptr(), _t_stride(t, S), out.data_ptr(), 4, out.data_ptr() + 12, 4, _ptr(dir_norm), R, S,
+                                           gt.data_ptr(), gscale, loss.data_ptr(), _ptr(Cr), d_out.data_ptr(), d_out.data_ptr() + 12,
+                                           _ptr(keep), ws.data_ptr(), _stream()), "hbr_composite_loss_fwd_bwd")
+    return loss, d_out, Cr
+
+
+def adam_step_multi(segments: Sequence[dict]):
+    """One launch of dense Adam/AdamW over up to four (p, g, m, v) segments: dicts with the keyword arguments of
+    adam_step (p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale)."""
+    segs = (_lib.AdamSegment * len(segments))()
+    for k, a in enumerate(segments):
+        require_gpu(a["p"])
+        segs[k] = _lib.AdamSegment(a["p"].data_ptr(), a["g"].data_ptr(), a["m"].data_ptr(), a["v"].data_ptr(), a["p"].numel(), a["lr"],
+                                   a["beta1"], a["beta2"], a["eps"], a["weight_decay"], a["step"], a.get("grad_scale", 1.0))
+    check(lib().hbr_adam_step_multi(len(segments), segs, _stream()), "hbr_adam_step_multi")
 
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
@@ -442,36 +518,58 @@ class RenderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rays_o, rays_d, t, dir_norm, geom, stacked, flat, precision, num_freq, splits, feat_dtype, n_tab, keep, *params):
-        o, d, t = _f32c(rays_o.detach()), _f32c(rays_d.detach()), _f32c(t.detach())
-        R, S = o.shape[0], t.shape[-1]
+        """t: depths [S] / [R,S], or a tuple (tn, tf, S, seed, offset): the shared depths are then drawn inside the
+        prologue launch (strat_sampler) and handed back as the fourth output."""
+        o, d = _f32c(rays_o.detach()), _f32c(rays_d.detach())
+        strat = None
+        if isinstance(t, tuple):
+            strat = (t[0], t[1], t[2], None, t[3], t[4])
+            t = None
+        else:
+            t = _f32c(t.detach())
+        R = o.shape[0]
         dn = _dir_norm_arg(dir_norm, R, o.device)
-        pe = dir_encode(d, num_freq)
+        if num_freq == 4:  # one launch: (depths,) direction encoding, weight-fragment image
+            t_new, pe = render_prologue(o.device, precision, params=flat, rays_d=d, strat=strat)
+            t = t if t is not None else t_new
+        else:
+            if strat is not None:
+                t = strat_sample(strat[0], strat[1], strat[2], o.device, seed=strat[4], offset=strat[5])
+            pe = dir_encode(d, num_freq)
+        S = t.shape[-1]
         if t.dim() == 1:
             x, rays = None, (o, d, t)
         else:
             x, rays = (o[:, None, :] + d[:, None, :] * t[:, :, None]).reshape(-1, 3).contiguous(), None
         feat = hash_encode_fwd(geom, stacked, x=x, rays=rays, layout=PLANAR, dtype=feat_dtype)
-        out = mlp_fwd(feat, PLANAR, pe, S, flat, precision, keep=keep)  # keep: occupancy mask [N] or None (all kept)
+        out = mlp_fwd(feat, PLANAR, pe, S, flat, precision, keep=keep, image_ready=None)  # keep: occupancy mask [N] or None (all kept)
         Cr, wts = composite_fwd(t, out.data_ptr(), 4, out.data_ptr() + 12, 4, dn, R, S)
         ctx.save_for_backward(o, d, t, pe, feat, out, flat)  # flat: see MlpFn
         ctx.x, ctx.keep = x, keep
         ctx.dn, ctx.geom, ctx.precision, ctx.splits, ctx.n_tab = dn, geom, precision, splits, n_tab
-        ctx.mark_non_differentiable(wts, out)
-        return Cr, wts, out
+        ctx.mark_non_differentiable(wts, out, t)
+        return Cr, wts, out, t
 
     @staticmethod
-    def backward(ctx, dCr, _dw, _dout):
+    def backward(ctx, dCr, _dw, _dout, _dt):
         o, d, t, pe, feat, out, flat = ctx.saved_tensors
         g = ctx.geom
         R, S = o.shape[0], t.shape[-1]
         d_out = torch.empty_like(out)
         composite_bwd(t, out.data_ptr(), 4, out.data_ptr() + 12, 4, ctx.dn, R, S, _f32c(dCr), d_out.data_ptr(), d_out.data_ptr() + 12,
                       keep=ctx.keep)
-        dflat = torch.zeros_like(flat)
+        # One flat [d tables | d MLP] buffer per backward, never zeroed: K4's finalize and K2's slab reduce WRITE every
+        # entry (`overwrite`; where K2 can only accumulate, hash_encode_bwd zeroes its slice itself).  The gradients
+        # handed to autograd are views of it: with `.grad` unset (zero_grad(set_to_none=True), train_hash2.py:233-234)
+        # AccumulateGrad adopts them without a copy.  A FRESH buffer each time - the caching allocator hands back the
+        # same block - because an adopted `.grad` may outlive this call.
+        n_tab = g.L * g.T * g.F
+        n_pad = (n_tab + flat.numel() + 3) // 4 * 4
+        gbuf = torch.empty(n_pad, dtype=torch.float32, device=o.device)
+        dtab, dflat = gbuf[:n_tab].view(g.L, g.T, g.F), gbuf[n_tab:n_tab + flat.numel()]
         amax = torch.empty(16, dtype=torch.float32, device=o.device) if g.L == 16 else None
-        dfeat = mlp_bwd(feat, PLANAR, pe, S, flat, ctx.precision, d_out, dflat, absmax_out=amax)
-        dtab = torch.zeros((g.L, g.T, g.F), dtype=torch.float32, device=o.device)
+        dfeat = mlp_bwd(feat, PLANAR, pe, S, flat, ctx.precision, d_out, dflat, absmax_out=amax, image_ready=None, overwrite=True)
         rays = None if ctx.x is not None else (o, d, t)
-        hash_encode_bwd(g, dfeat, dtab, x=ctx.x, rays=rays, layout=PLANAR, dy_absmax=amax)
+        hash_encode_bwd(g, dfeat, dtab, x=ctx.x, rays=rays, layout=PLANAR, dy_absmax=amax, overwrite=True)
         grads = tuple(dtab[i] for i in range(ctx.n_tab)) + tuple(dflat[a:b].view(shape) for (a, b, shape) in ctx.splits)
         return (None,) * 13 + grads

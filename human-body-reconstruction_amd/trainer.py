@@ -77,6 +77,10 @@ class HashNeRFTrainer:
         self.step_count = 0
         self.last_loss = None
         self.timers = None  # optional dict name -> list[(start_event, end_event)], filled when set by bench.py
+        # the step's small launches folded together: prologue (depths + direction encoding + weight image), compositing +
+        # loss + compositing backward, one Adam launch.  HBR_FUSED_SMALL=0: the separate launches (A/B, tests).
+        import os
+        self.fused_small = os.environ.get("HBR_FUSED_SMALL", "1") != "0"
 
     # ---- helpers ------------------------------------------------------------------------------
     def _bind_parameters(self):
@@ -109,19 +113,29 @@ class HashNeRFTrainer:
         self._bind_parameters()
         S, g = self.S, self.geom
         R = rays_o.shape[0]
-        if t is None:
-            t = self.sample_t(rays_o.device)
         dn = dir_norm.reshape(-1) if torch.is_tensor(dir_norm) else None
+        fused = self.fused_small and self.num_freq == 4
+        if fused:
+            # ONE launch: this step's depths (unless given), the direction encoding, the MLP's weight-fragment image
+            strat = None if t is not None else (self.near, self.far, S, None, self.seed, self.step_count)
+            t_new, pe = ops.render_prologue(rays_o.device, self.precision, params=self.flat, rays_d=rays_d, strat=strat)
+            t = t if t is not None else t_new
+        else:
+            if t is None:
+                t = self.sample_t(rays_o.device)
+            pe = ops.dir_encode(rays_d, self.num_freq)
         rays = (rays_o, rays_d, t)
         # forward
-        pe = ops.dir_encode(rays_d, self.num_freq)
         feat = self._timed("hash_fwd", lambda: ops.hash_encode_fwd(g, self.tables, rays=rays, layout=PLANAR, dtype=self.feat_dtype))
-        out = self._timed("mlp_fwd", lambda: ops.mlp_fwd(feat, PLANAR, pe, S, self.flat, self.precision))
-        Cr, _ = ops.composite_fwd(t, out.data_ptr(), 4, out.data_ptr() + 12, 4, dn, R, S, want_wts=False)
-        # loss + backward
-        loss, dCr = ops.mse2_loss(Cr, gt)
-        d_out = torch.empty_like(out)
-        ops.composite_bwd(t, out.data_ptr(), 4, out.data_ptr() + 12, 4, dn, R, S, dCr, d_out.data_ptr(), d_out.data_ptr() + 12)
+        out = self._timed("mlp_fwd", lambda: ops.mlp_fwd(feat, PLANAR, pe, S, self.flat, self.precision, image_ready=fused))
+        if fused:
+            # ONE launch: compositing, loss = 2*MSE and its gradient, compositing backward (each ray in its own wave)
+            loss, d_out, _ = ops.composite_loss_fwd_bwd(t, out, dn, R, S, gt)
+        else:
+            Cr, _ = ops.composite_fwd(t, out.data_ptr(), 4, out.data_ptr() + 12, 4, dn, R, S, want_wts=False)
+            loss, dCr = ops.mse2_loss(Cr, gt)
+            d_out = torch.empty_like(out)
+            ops.composite_bwd(t, out.data_ptr(), 4, out.data_ptr() + 12, 4, dn, R, S, dCr, d_out.data_ptr(), d_out.data_ptr() + 12)
         # No memset of the 8 MiB gradient buffer: K4 and K2 WRITE their outputs (`overwrite`; where K2 runs a path that
         # can only accumulate, ops zeroes that slice itself).  The padding behind the MLP block is never written.
         # K4 also reports max |d feat| per level: K2's fixed-point scale, without K2 re-reading the buffer for it
@@ -165,10 +179,16 @@ class HashNeRFTrainer:
         k = self.step_count
         gs = 1.0 / self.world
         nt = self.n_tab
-        ops.adam_step(self.tables.view(-1), self.grad[:nt], self.m[:nt], self.v[:nt],
-                      cosine_lr(self.lr_embed, self.eta_min, k, self.total_steps), 0.9, 0.999, 1e-8, 0.0, k + 1, gs)
-        ops.adam_step(self.flat, self.g_mlp, self.m[nt:nt + MLP_PARAM_FLOATS], self.v[nt:nt + MLP_PARAM_FLOATS],
-                      cosine_lr(self.lr_mlp, self.eta_min, k, self.total_steps), 0.9, 0.999, 1e-8, self.wd_mlp, k + 1, gs)
+        tab = dict(p=self.tables.view(-1), g=self.grad[:nt], m=self.m[:nt], v=self.v[:nt],
+                   lr=cosine_lr(self.lr_embed, self.eta_min, k, self.total_steps), weight_decay=0.0)
+        mlp = dict(p=self.flat, g=self.g_mlp, m=self.m[nt:nt + MLP_PARAM_FLOATS], v=self.v[nt:nt + MLP_PARAM_FLOATS],
+                   lr=cosine_lr(self.lr_mlp, self.eta_min, k, self.total_steps), weight_decay=self.wd_mlp)
+        common = dict(beta1=0.9, beta2=0.999, eps=1e-8, step=k + 1, grad_scale=gs)
+        if self.fused_small:  # Adam on the tables + AdamW on the MLP in ONE launch
+            ops.adam_step_multi([{**tab, **common}, {**mlp, **common}])
+        else:
+            ops.adam_step(**tab, **common)
+            ops.adam_step(**mlp, **common)
         self.step_count += 1
         self.last_loss = loss
         return loss

@@ -43,7 +43,11 @@ class Volume_Renderer():
         self.reset_mask = False
         self.use_sdf = use_sdf
         self.var_model = var_model
-        self.feat_dtype = F32       # dtype of the planar feature buffer between K1 and K3 (F32 | BF16)
+        # dtype of the planar feature / feature-gradient buffers between K1, K3/K4 and K2 (internal: never handed to
+        # the caller).  None = the MLP's precision: under autocast the MLP's MFMA fragments are bf16 whatever the
+        # storage (bit-identical forward), and autocast hands the Linear-input gradient back in half precision too
+        # ("Precision switch"); F32 keeps both buffers fp32.
+        self.feat_dtype = None
         self._grid_key = None       # (tensor identity, storage, version) the cached all-true answer belongs to
         self._grid_all_true = True
         self.fine_rng = None        # optional callable -> (u [R,S], samples01 [S]) replacing torch.rand in the hierarchical pass
@@ -96,18 +100,24 @@ class Volume_Renderer():
             raise NotImplementedError("direction encoder must be PositionalEncoder(d_model=3, num_freq=4) (train_hash2.py:46,121)")
         if not rays_d.is_cuda:
             raise HbrError("vol_render needs rays on the MI355X; there is no CPU fallback")
-        if t is None:
-            t = strat_sampler(self.near, self.far, num_samples, device=rays_d.device)
         if update_mask is True and self.reset_mask is True:  # vol_renderer.py:201-203
             self.bool_grid[...] = False
             self.reset_mask = False
         # masked branch (vol_renderer.py:209-221) unless update_mask, or the grid has no False cell to look up
         keep = None
-        if update_mask is not True and not self._mask_is_trivial():
+        need_mask = update_mask is not True and not self._mask_is_trivial()
+        if t is None:
+            if need_mask or denc.max_seq_len != 4:
+                t = strat_sampler(self.near, self.far, num_samples, device=rays_d.device)
+            else:  # drawn inside the render's prologue launch, from the same generator state strat_sampler would use
+                from .helper import _take_cuda_philox
+                seed, off = _take_cuda_philox(rays_d.device, num_samples)
+                t = (float(self.near), float(self.far), int(num_samples), seed, off)
+        if need_mask:
             g = self.bool_grid if self.bool_grid.is_contiguous() else self.bool_grid.contiguous()
             mu = self.mu.detach().float().reshape(-1).cpu().tolist()
             keep = ops.occupancy_mask(g, mu * 3 if len(mu) == 1 else mu, float(self.sigma_val), rays=(rays_o, rays_d, t))
-        Cr = self._render_fused(mlp, rays_d, rays_o, t, dir_norm, keep)
+        Cr, t = self._render_fused(mlp, rays_d, rays_o, t, dir_norm, keep)
         if hierarchical is True:
             from .hierarchical import render_fine
             Cf = render_fine(self, mlp, rays_d, rays_o, t, self._last_wts, num_samples, dir_norm)
@@ -120,11 +130,12 @@ class Volume_Renderer():
         stacked = enc.stacked_tables()
         flat, splits = mlp.flat_params()
         tabs = [lvl.weight for lvl in enc.Embedding_list]
-        Cr, wts, out = ops.RenderFn.apply(rays_o, rays_d, t, dir_norm, enc.geometry(), stacked, flat,
-                                          ops.precision_from_autocast(), self.Dir_encode.max_seq_len, splits, self.feat_dtype,
+        prec = ops.precision_from_autocast()
+        Cr, wts, out, t = ops.RenderFn.apply(rays_o, rays_d, t, dir_norm, enc.geometry(), stacked, flat,
+                                          prec, self.Dir_encode.max_seq_len, splits, prec if self.feat_dtype is None else self.feat_dtype,
                                           len(tabs), keep, *tabs, *mlp._ordered())
         R, S = rays_o.shape[0], t.shape[0]
         self._last_wts = wts
         o4 = out.view(R, S, 4)
         self.last_sigma, self.last_rgb = o4[..., 3], o4[..., 0:3]
-        return Cr
+        return Cr, t

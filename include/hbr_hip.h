@@ -45,9 +45,9 @@ enum {
 };
 
 enum { HBR_F32 = 0, HBR_BF16 = 1 };
-/* OR-ed into hbr_mlp_bwd's `precision`: the workspace still holds the weight-fragment image that the previous
- * hbr_mlp_fwd / hbr_mlp_bwd call built from the same `params` at the same precision (forward then backward of one
- * training step), so the backward need not pack it again. */
+/* OR-ed into hbr_mlp_fwd's / hbr_mlp_bwd's `precision`: the workspace still holds the weight-fragment image that the
+ * previous hbr_render_prologue / hbr_mlp_fwd / hbr_mlp_bwd call built from the same `params` at the same precision
+ * (prologue, forward, then backward of one training step), so this call need not pack it again. */
 enum { HBR_IMAGE_READY = 0x100 };
 /* OR-ed into hbr_hash_encode_bwd's `algo` and hbr_mlp_bwd's `precision`: the gradient outputs (dtables / dparams) are
  * WRITTEN instead of accumulated into, so the caller need not zero them first (a training step's 8 MiB memset).
@@ -77,6 +77,18 @@ HBR_API int hbr_strat_sample(float tn, float tf, int64_t S, const float* u, uint
 HBR_API int hbr_occupancy_mask(const float* x, const float* rays_o, const float* rays_d, const float* t, int64_t R,
                        int64_t S, const uint8_t* grid, int G, const float* mu_host, float sigma_val,
                        uint8_t* keep, void* stream);
+
+/* ---- K0 + a7 + weight packing in ONE launch ---------------------------------------------------------
+ * What a render call does before the encoder runs (vol_renderer.py:163,177-181 + the MLP's weight staging):
+ *   t      [S] out as hbr_strat_sample(tn, tf, S, u, seed, offset) writes it; NULL: skipped
+ *   pe     [R,24] out = hbr_dir_encode(rays_d [R,3], d_model 3, num_freq 4); NULL (with rays_d NULL): skipped
+ *   params the MLP's flat parameter block (see hbr_mlp_fwd): its MFMA-fragment image is built in `ws`
+ *          (hbr_mlp_workspace_bytes(precision) bytes) exactly as hbr_mlp_fwd builds it; a following hbr_mlp_fwd /
+ *          hbr_mlp_bwd on this stream with HBR_IMAGE_READY then skips its own packing launch.  NULL: skipped.
+ */
+HBR_API int hbr_render_prologue(float tn, float tf, int64_t S, const float* u, uint64_t seed, uint64_t offset, float* t,
+                                const float* rays_d, int64_t R, float* pe, const float* params, int precision, void* ws,
+                                int64_t ws_bytes, void* stream);
 
 /* ---- K1: multiresolution hash-grid encode --------------------------------------------------
  * Replaces HashEncoder.forward, hash_encoding.py:146-170 (per level: scale :153-154, trunc :157,
@@ -148,6 +160,20 @@ HBR_API int hbr_composite_fwd(const float* t, int64_t t_stride, const float* rgb
 HBR_API int hbr_composite_bwd(const float* t, int64_t t_stride, const float* rgb, int64_t rgb_stride, const float* sigma,
                       int64_t sigma_stride, const float* dir_norm, int64_t R, int64_t S,
                       const float* dCr, float* d_rgb, float* d_sigma, const uint8_t* keep, void* stream);
+
+/* ---- K5 forward + a11 + K5 backward in ONE launch (the fused training step) ----------------------------------
+ * hbr_composite_fwd, hbr_mse2_loss_fwd_bwd and hbr_composite_bwd for the case Cf is Cr (hierarchical off): a ray's
+ * colour, its share of loss = 2*mean((Cr-gt)^2) and the gradient dCr = gscale*4*(Cr-gt)/(3R) flowing back into its own
+ * samples are computed by one wave in one pass.  Arguments as in those three calls, except:
+ *   loss_out  one fp32, WRITTEN (block sums added in a fixed order by a one-wave second launch: bitwise reproducible)
+ *   Cr        [R,3] out, or NULL when the colours themselves are not needed
+ *   ws        hbr_composite_loss_workspace_bytes(R) bytes of scratch (the block sums), dead after the call
+ */
+HBR_API int64_t hbr_composite_loss_workspace_bytes(int64_t R);
+HBR_API int hbr_composite_loss_fwd_bwd(const float* t, int64_t t_stride, const float* rgb, int64_t rgb_stride,
+                                       const float* sigma, int64_t sigma_stride, const float* dir_norm, int64_t R,
+                                       int64_t S, const float* gt, float gscale, float* loss_out, float* Cr,
+                                       float* d_rgb, float* d_sigma, const uint8_t* keep, void* ws, void* stream);
 
 /* ---- a7: view-direction encoding ---------------------------------------------------------------
  * Replaces PositionalEncoder.forward, encoder.py:25-32: for each row and coordinate c,
@@ -222,6 +248,20 @@ HBR_API int hbr_mse2_loss_fwd_bwd(const float* Cr, const float* gt, int64_t R, f
 HBR_API int hbr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
                   void* stream);
+
+/* The same for up to four parameter segments in ONE launch (a training step's Adam on the tables + AdamW on the MLP,
+ * train_hash2.py:227-228): segs_host is a HOST array of nseg descriptors, field meanings as hbr_adam_step's arguments. */
+typedef struct HbrAdamSegment {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int64_t n;
+  float lr, beta1, beta2, eps, weight_decay;
+  int64_t step;
+  float grad_scale;
+} HbrAdamSegment;
+HBR_API int hbr_adam_step_multi(int nseg, const HbrAdamSegment* segs_host, void* stream);
 
 #ifdef __cplusplus
 }
