@@ -43,6 +43,9 @@ SIGNATURES = {
     "hbr_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _l, _f, _p]),
     "hbr_adam_step_multi": (_i, [_i, _p, _p]),
     "hbr_render_prologue": (_i, [_f, _f, _l, _p, C.c_uint64, C.c_uint64, _p, _p, _l, _p, _p, _i, _p, _l, _p]),
+    "hbr_hierarchical_resample": (_i, [_p, _p, _l, _p, _p, C.c_uint64, C.c_uint64, _f, _f, _l, _l, _l, _p, _p]),
+    "hbr_occupancy_update_workspace_bytes": (_l, [_i]),
+    "hbr_occupancy_update": (_i, [_p, _p, _p, _p, _l, _l, _p, _p, _p, _i, _p, _f, _p, _l, _p]),
     "hbr_composite_loss_workspace_bytes": (_l, [_l]),
     "hbr_composite_loss_fwd_bwd": (_i, [_p, _l, _p, _l, _p, _l, _p, _l, _l, _p, _f, _p, _p, _p, _p, _p, _p, _p]),
 }

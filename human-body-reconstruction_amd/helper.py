@@ -70,22 +70,14 @@ def hierarchical_sampling(rays_o: torch.Tensor, rays_d: torch.Tensor, z_vals: to
     """Inverse-CDF resampling of the reference's second pass (helper.py:23-51).  Returns (points [R, S+n, 3],
     combined depths [R, S+n]).  Negative weights count as 0; the new depths index ONE shared random vector
     `samples` of length n_samples (the reference's behaviour, helper.py:43-45), then merge-sort with z_vals.
-    `u` [R,S] / `samples01` [n] optionally supply the two uniform draws (parity tests); default: torch.rand."""
-    dev = weights.device
+    `u` [R,S] / `samples01` [n] optionally supply the two uniform draws (parity tests); default: drawn on the device
+    from torch's CUDA generator state (manual_seed replays them).  One kernel, one wave per ray
+    (hbr_hierarchical_resample) - no cumsum / searchsorted / cat / sort launches."""
     w = weights.detach().reshape(weights.shape[0], -1)
-    w = torch.where(w < 0, torch.zeros_like(w), w)
-    pdf = (w + 1e-5) / torch.sum(w + 1e-5, dim=-1, keepdim=True)
-    cdf = torch.cumsum(pdf, dim=-1)
-    if u is None:
-        u = torch.rand(cdf.shape, device=dev)
-    inds = torch.searchsorted(cdf, u.contiguous(), right=True)
-    if samples01 is None:
-        samples01 = torch.rand(n_samples, device=dev)
-    samples = samples01 * (float(tf) - float(tn)) + float(tn)
-    inds = torch.clamp(inds, min=0, max=samples.shape[-1] - 1)
-    samples = samples[inds]
-    z = z_vals.expand(list(inds.shape[:-1]) + [z_vals.shape[-1]])
-    combined, _ = torch.sort(torch.cat([z, samples], dim=-1), dim=-1)
+    seed = off = 0
+    if u is None or samples01 is None:
+        seed, off = _take_cuda_philox(w.device, w.numel() + n_samples)
+    combined = ops.hierarchical_resample(w, z_vals, n_samples, float(tn), float(tf), u=u, samples01=samples01, seed=seed, offset=off)
     rays = rays_o[..., None, :] + rays_d[..., None, :] * combined[..., :, None]
     return rays, combined
 

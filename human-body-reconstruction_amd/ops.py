@@ -349,6 +349,57 @@ def occupancy_mask(grid: torch.Tensor, mu, sigma_val: float, x: Optional[torch.T
     return keep
 
 
+def occupancy_update(grid: torch.Tensor, mu, sigma_val: float, alpha: torch.Tensor, x: Optional[torch.Tensor] = None, rays=None,
+                     tmp_arr: Optional[torch.Tensor] = None) -> None:
+    """Volume_Renderer.update_grid (vol_renderer.py:116-131) in place on `grid` ([G,G,G] bool/uint8): see hbr_hip.h."""
+    require_gpu(grid)
+    if grid.dtype not in (torch.bool, torch.uint8) or grid.dim() != 3 or not grid.is_contiguous() or len(set(grid.shape)) != 1:
+        raise HbrError("occupancy grid must be a contiguous cubic bool/uint8 tensor")
+    if tmp_arr is not None and (tmp_arr.dtype != torch.int8 or tmp_arr.shape != grid.shape or not tmp_arr.is_contiguous()):
+        raise HbrError("tmp_arr must be a contiguous int8 tensor of the grid's shape")
+    import ctypes as C
+    if x is not None:
+        x = _f32c(x)
+        R, S = x.shape[0], 1
+        o = d = t = None
+    else:
+        o, d, t = (_f32c(a) for a in rays)
+        R, S = o.shape[0], t.shape[0]
+    alpha = _f32c(alpha).reshape(-1)
+    if alpha.numel() != R * S:
+        raise HbrError("alpha must hold one value per point")
+    G = grid.shape[0]
+    ws = _workspace("occ_update", lib().hbr_occupancy_update_workspace_bytes(G), grid.device)
+    m = (C.c_float * 3)(*[float(v) for v in mu])
+    check(lib().hbr_occupancy_update(_ptr(x), _ptr(o), _ptr(d), _ptr(t), R, S, alpha.data_ptr(), grid.data_ptr(), _ptr(tmp_arr), G, m,
+                                     float(sigma_val), ws.data_ptr(), ws.numel(), _stream()), "hbr_occupancy_update")
+
+
+def hierarchical_resample(weights: torch.Tensor, z_vals: torch.Tensor, n_samples: int, tn: float, tf: float,
+                          u: Optional[torch.Tensor] = None, samples01: Optional[torch.Tensor] = None, seed: int = 0, offset: int = 0) -> torch.Tensor:
+    """t_fine [R, 2S] of hierarchical_sampling (helper.py:23-51): weights [R,S] (or [R,S,1]), z_vals [S] or [R,S];
+    u [R,S] / samples01 [n]: the two uniform draws, or None: drawn on the device from (seed, offset)."""
+    require_gpu(weights)
+    w = _f32c(weights.detach()).reshape(weights.shape[0], -1)
+    R, S = w.shape
+    z = _f32c(z_vals.detach())
+    if z.dim() == 2 and tuple(z.shape) != (R, S) or z.dim() == 1 and z.shape[0] != S:
+        raise HbrError("z_vals must be [S] or [R,S]")
+    if u is not None:
+        u = _f32c(u)
+        if tuple(u.shape) != (R, S):
+            raise HbrError("u must be [R,S]")
+    if samples01 is not None:
+        samples01 = _f32c(samples01)
+        if samples01.numel() != n_samples:
+            raise HbrError("samples01 must hold n_samples draws")
+    out = torch.empty((R, 2 * S), dtype=torch.float32, device=w.device)
+    check(lib().hbr_hierarchical_resample(w.data_ptr(), z.data_ptr(), 0 if z.dim() == 1 else S, _ptr(u), _ptr(samples01),
+                                          int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), float(tn), float(tf), R, S, int(n_samples),
+                                          out.data_ptr(), _stream()), "hbr_hierarchical_resample")
+    return out
+
+
 def render_fwd(geom: HashGeom, tables: torch.Tensor, params: torch.Tensor, rays_o, rays_d, t, dir_norm=None, precision: int = F32,
                feat_dtype: int = F32, keep: Optional[torch.Tensor] = None, want_wts: bool = False, want_out: bool = False):
     """Inference render of R rays at the shared depths t[S] in one library call (no autograd): returns (Cr [R,3],

@@ -61,14 +61,11 @@ class Volume_Renderer():
         return (p * self.grid_size).long()
 
     def update_grid(self, points: torch.Tensor, alpha: torch.Tensor):
-        idx = self._cell(points)
-        alpha = torch.where(alpha <= 0, torch.zeros_like(alpha), alpha)
-        self.tmp_arr[idx[..., 0], idx[..., 1], idx[..., 2]] += torch.ceil(alpha).to(torch.int8)
-        if torch.sum(self.tmp_arr > 0) == 0:
-            self.bool_grid[...] = True
-        else:
-            self.bool_grid[self.tmp_arr > 0] = True
-        self.tmp_arr[self.tmp_arr > 0] = 0
+        """vol_renderer.py:116-131 on the device (hbr_occupancy_update): a cell becomes True iff the last point falling
+        into it has int8(tmp_arr[cell] + ceil(max(alpha, 0))) > 0; no cell set at all => the whole grid True."""
+        mu = self.mu.detach().float().reshape(-1).cpu().tolist()
+        ops.occupancy_update(self.bool_grid, mu * 3 if len(mu) == 1 else mu, float(self.sigma_val), alpha, x=points.reshape(-1, 3),
+                             tmp_arr=self.tmp_arr)
 
     def get_mask(self, points: torch.Tensor) -> torch.Tensor:
         idx = self._cell(points)

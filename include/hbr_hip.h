@@ -78,6 +78,33 @@ HBR_API int hbr_occupancy_mask(const float* x, const float* rays_o, const float*
                        int64_t S, const uint8_t* grid, int G, const float* mu_host, float sigma_val,
                        uint8_t* keep, void* stream);
 
+/* ---- a13 / f4: resampling for the hierarchical second pass --------------------------------------------------
+ * Replaces hierarchical_sampling, helper.py:23-51 (one wave per ray; torch cumsum / searchsorted / cat / sort otherwise):
+ *   weights [R,S] the first pass's compositing weights (negative values count as 0, :36)
+ *   z_vals  the first pass's depths: [S] shared (z_stride = 0) or [R, z_stride >= S]
+ *   u       [R,S] uniform draws for the inverse-CDF lookup, or NULL: Philox4x32-10 from (seed, offset), stream 1
+ *   samples01 [n_samples] uniform draws of the ONE depth vector all rays index (:43-45), or NULL: Philox stream 2
+ *   t_fine  [R, 2S] out: sort(cat(z_vals, samples[clamp(searchsorted(cdf, u, right=True), 0, n_samples-1)])) - a ray
+ *           gets S new depths (u has the cdf's shape) whatever n_samples is
+ * pdf and cdf are summed sequentially in fp32 (as torch's CPU cumsum does): the lookup is discontinuous in the cdf's
+ * last bit. */
+HBR_API int hbr_hierarchical_resample(const float* weights, const float* z_vals, int64_t z_stride, const float* u,
+                                      const float* samples01, uint64_t seed, uint64_t offset, float tn, float tf,
+                                      int64_t R, int64_t S, int64_t n_samples, float* t_fine, void* stream);
+
+/* ---- f4: occupancy-grid update ----------------------------------------------------------------------------------
+ * Replaces Volume_Renderer.update_grid, vol_renderer.py:116-131, on the [G,G,G] byte grid hbr_occupancy_mask reads:
+ * a cell is set to True iff the LAST point (in point order) that falls into it has int8(ceil(max(alpha, 0))) > 0 - the
+ * reference's non-accumulating index_put through an int8 scratch array, wrap-around included; if no cell gets set the
+ * whole grid becomes True (:126-127).  Cells are never cleared.  Points as in K1 (x, or rays_o / rays_d / t);
+ * alpha [N] fp32 (the reference passes the model's density column).  tmp_arr: the reference's [G,G,G] int8 scratch,
+ * state carried between calls (a count that wrapped negative survives the reset at :131), or NULL (treated as zeros).
+ * ws: hbr_occupancy_update_workspace_bytes(G). */
+HBR_API int64_t hbr_occupancy_update_workspace_bytes(int G);
+HBR_API int hbr_occupancy_update(const float* x, const float* rays_o, const float* rays_d, const float* t, int64_t R,
+                                 int64_t S, const float* alpha, uint8_t* grid, int8_t* tmp_arr, int G,
+                                 const float* mu_host, float sigma_val, void* ws, int64_t ws_bytes, void* stream);
+
 /* ---- K0 + a7 + weight packing in ONE launch ---------------------------------------------------------
  * What a render call does before the encoder runs (vol_renderer.py:163,177-181 + the MLP's weight staging):
  *   t      [S] out as hbr_strat_sample(tn, tf, S, u, seed, offset) writes it; NULL: skipped

@@ -378,6 +378,36 @@ def main():
         g14["p." + k] = v.numpy()
     np.savez_compressed(os.path.join(OUT, "g14_vanilla_nerf.npz"), **g14)
 
+    # ---------------- G16: Volume_Renderer.update_grid (vol_renderer.py:116-131) --------------------------------
+    # Called directly on the reference's object, grid 16^3 (max_dim 64), bool_grid cleared first so that what the update
+    # SETS is visible.  Three calls in a row on the same object (tmp_arr carries state): (1) a mix of alpha <= 0,
+    # fractional, ordinary and > 127 values (ceil(alpha) wraps in the int8 scratch) with many points per cell (the
+    # non-accumulating index_put: the LAST point of a cell decides); (2) the same points, new alphas - cells whose count
+    # wrapped negative in (1) start from that value; (3) nothing positive at all -> the whole grid becomes True.
+    rg = np.random.default_rng(1616)
+    mu16 = np.array([-1.0, -0.5, 0.25], dtype=np.float32)
+    vr16 = ref.vol_renderer.Volume_Renderer(H=8, W=8, K=Kd, near=2.0, far=6.0, device="cpu", Pos_encode=None, Dir_encode=None,
+                                            max_dim=64, sigma_val=torch.tensor(3.0), mu=torch.from_numpy(mu16))
+    pts16 = f32(mu16 + rg.uniform(0.02, 2.9, (3000, 3)))
+    def alphas(k):
+        a = rg.normal(0.3, 1.0, 3000)
+        a[rg.uniform(0, 1, 3000) < 0.1] = 0.0
+        big = rg.uniform(0, 1, 3000) < 0.06
+        a[big] = rg.uniform(100, 400, int(big.sum()))
+        return f32(a)
+    g16 = dict(points=pts16, mu=mu16, sigma_val=np.float32(3.0), grid_size=vr16.grid_size)
+    vr16.bool_grid[...] = False
+    for k in range(3):
+        a = alphas(k) if k < 2 else f32(-np.abs(rg.normal(0, 1, 3000)))
+        g16[f"alpha{k}"] = a.copy()
+        if k == 2:
+            vr16.bool_grid[...] = False
+            vr16.tmp_arr[...] = 0
+        vr16.update_grid(torch.from_numpy(pts16.copy()), torch.from_numpy(a.copy()))
+        g16[f"grid{k}"] = vr16.bool_grid.numpy().copy()
+        g16[f"tmp{k}"] = vr16.tmp_arr.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "g16_update_grid.npz"), **g16)
+
     # ---------------- G10: PSNR + bounding box -----------------------------------------
     a = torch.from_numpy(f32(rng.uniform(0, 1, (50, 3))))
     b = torch.from_numpy(f32(rng.uniform(0, 1, (50, 3))))

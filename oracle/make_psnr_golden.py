@@ -115,7 +115,8 @@ def merge(files):
     for z in runs:
         assert int(z["eval_steps"][-1]) == int(z["steps"]), f"seed {int(z['seed'])} did not finish"
     np.savez(OUT, seeds=np.array([int(z["seed"]) for z in runs]), steps=steps.pop(), eval_steps=ev,
-             psnr=np.stack([z["psnr"] for z in runs]), loss_tail=np.stack([z["loss"][-64:] for z in runs]),
+             psnr=np.stack([z["psnr"] for z in runs]), loss_head=np.stack([z["loss"][:16] for z in runs]),
+             loss_tail=np.stack([z["loss"][-64:] for z in runs]),
              input_checksum=np.array([float(z["input_checksum"]) for z in runs]),
              scene_checksum=float(runs[0]["scene_checksum"]),
              config=np.array([R, S, L, T, NB, EVAL_RAYS, EVAL_SEED, BATCH_SEED0, BBOX_SEED]))

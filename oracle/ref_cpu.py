@@ -273,6 +273,30 @@ def occupancy_mask(pts: torch.Tensor, grid: torch.Tensor, mu, sigma_val) -> torc
     return grid[c[..., 0], c[..., 1], c[..., 2]]
 
 
+def update_grid(pts: torch.Tensor, alpha: torch.Tensor, grid: torch.Tensor, tmp: torch.Tensor, mu, sigma_val) -> None:
+    """Volume_Renderer.update_grid (vol_renderer.py:116-131), in place on `grid` (bool [G,G,G]) and `tmp` (int8 [G,G,G]),
+    with the effect of its tensor ops spelled out: alpha <= 0 counts as 0 (:121); `tmp[cell] += ceil(alpha).int()` is an
+    index_put WITHOUT accumulation through an int8 array, so of the points sharing a cell the LAST one (in point order)
+    decides, every one of them having read the cell's OLD value, and the int32 sum wraps into int8 (:123); cells whose
+    count is > 0 become True, or the whole grid if there is none (:125-128); positive counts are reset to 0, a count
+    that wrapped negative is not (:131)."""
+    G = grid.shape[0]
+    c = (((pts - mu) / sigma_val) * G).long().numpy()
+    a = alpha.numpy()
+    v = np.where(a <= 0, 0.0, np.ceil(a)).astype(np.int64)
+    t = tmp.numpy()
+    old = t.copy()
+    for n in range(c.shape[0]):  # sequential: a later point overwrites an earlier one's cell
+        i, j, k = c[n]
+        t[i, j, k] = np.int64(old[i, j, k] + v[n]).astype(np.int8)
+    pos = t > 0
+    if pos.sum() == 0:
+        grid[...] = True
+    else:
+        grid[torch.from_numpy(pos)] = True
+    t[pos] = 0
+
+
 def block_pattern_grid(G: int = 256) -> torch.Tensor:
     """The mixed occupancy grid of golden G13: blocks of 8^3 cells, False where (bx + 2 by + 3 bz) % 3 == 0."""
     b = torch.arange(G) // 8

@@ -261,3 +261,19 @@ def test_config1_plumbing_at_baseline_size():
         Cr, sig, rgb = ref_cpu.render_vanilla(o, d, t, dn, ref_cpu.vanilla_nerf_init(0))
     assert Cr.shape == (R, 3) and sig.shape == (R, S) and rgb.shape == (R, S, 3)
     assert bool(torch.isfinite(Cr).all()) and float(sig.min()) >= 0.0 and float(sig.max()) <= 1.0 and float(rgb.min()) >= 0.0
+
+
+def test_update_grid_vs_reference(golden):
+    """G16: Volume_Renderer.update_grid called directly on the reference's object, three calls in a row (state in tmp_arr)."""
+    g = golden("g16_update_grid.npz")
+    G = int(g["grid_size"])
+    grid, tmp = torch.zeros((G, G, G), dtype=torch.bool), torch.zeros((G, G, G), dtype=torch.int8)
+    pts, mu, sv = torch.from_numpy(g["points"]), torch.from_numpy(g["mu"]), torch.tensor(float(g["sigma_val"]))
+    for k in range(3):
+        if k == 2:
+            grid[...] = False
+            tmp[...] = 0
+        ref_cpu.update_grid(pts, torch.from_numpy(g[f"alpha{k}"]), grid, tmp, mu, sv)
+        assert np.array_equal(grid.numpy(), g[f"grid{k}"]), k
+        assert np.array_equal(tmp.numpy(), g[f"tmp{k}"]), k
+    assert (g["tmp0"] < 0).sum() > 10 and g["grid2"].all() and 0 < g["grid0"].sum() < g["grid1"].sum() < G ** 3
