@@ -139,8 +139,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--feat-dtype", default="auto", choices=["auto", "f32", "bf16"],
                     help="storage of the feature / feature-gradient buffers between the hash and MLP kernels (auto: the MLP precision)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: --rays per rank; strong: --rays in total, split over the ranks")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong", "both"],
+                    help="weak: --rays per rank; strong: --rays in total, split over the ranks; both: one JSON line each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the reference-loop-on-drop-in-classes leg (N=1 only)")
@@ -181,115 +181,148 @@ def main():
             torch.distributed.init_process_group(backend)
     assert _lib.lib().hbr_device_ok() == 1, "not a gfx950 device"
 
-    S = args.samples
-    R = args.rays if args.scaling == "weak" else args.rays // world  # rays per rank per step
-    if R < 1:
-        raise SystemExit("--scaling strong: fewer rays than ranks")
-    # ---- synthetic lego-shaped workload, resident in HBM ---------------------------------
-    # a pool of pre-shuffled ray batches per rank; the bbox comes from a fixed seed so every rank agrees on it
-    o0, d0, _, _ = synthetic.hemisphere_rays(65536, seed=0)
-    mn, mx, sig = synthetic.ray_bbox(o0, d0, 2.0, 6.0)
-    pool = 8
-    batches = []
-    for b in range(pool):
-        # rays toward the object from the upper hemisphere; ground truth = the analytic solid of synthetic.solid_field
-        # composited on a fine quadrature (a consistent radiance field, so the loss/PSNR of the run mean something)
-        o, d, dn, gt = synthetic.scene_rays(R, seed=1000 + rank * pool + b, device=dev)
-        batches.append(tuple(a.contiguous() for a in (o, d, dn.reshape(-1), gt)))
-    enc, denc, mlp = build_default_model(mn, sig, dev, seed=0)  # same init on every rank (replicated parameters)
-    prec = _lib.BF16 if args.precision == "bf16" else _lib.F32
-    fdt = prec if args.feat_dtype == "auto" else (_lib.BF16 if args.feat_dtype == "bf16" else _lib.F32)
-    total_steps = 4000 * 1000  # train_hash2.py:156-157: epochs * len(loader) (1000 epochs x 4000 batches of the 64M lego rays)
-    tr = HashNeRFTrainer(enc, mlp, near=2.0, far=6.0, num_samples=S, total_steps=total_steps, precision=prec, feat_dtype=fdt,
-                         overlap_comm=os.environ.get("HBR_OVERLAP_COMM", "1") != "0")  # A/B switch for the staged all-reduce
-    torch.manual_seed(1234)  # identical jitter t[S] on every rank
+    def run(scaling):
+        S = args.samples
+        R = args.rays if scaling == "weak" else args.rays // world  # rays per rank per step
+        if R < 1:
+            raise SystemExit("--scaling strong: fewer rays than ranks")
+        # ---- synthetic lego-shaped workload, resident in HBM ---------------------------------
+        # a pool of pre-shuffled ray batches per rank; the bbox comes from a fixed seed so every rank agrees on it
+        o0, d0, _, _ = synthetic.hemisphere_rays(65536, seed=0)
+        mn, mx, sig = synthetic.ray_bbox(o0, d0, 2.0, 6.0)
+        pool = 8
+        batches = []
+        for b in range(pool):
+            # rays toward the object from the upper hemisphere; ground truth = the analytic solid of synthetic.solid_field
+            # composited on a fine quadrature (a consistent radiance field, so the loss/PSNR of the run mean something)
+            o, d, dn, gt = synthetic.scene_rays(R, seed=1000 + rank * pool + b, device=dev)
+            batches.append(tuple(a.contiguous() for a in (o, d, dn.reshape(-1), gt)))
+        enc, denc, mlp = build_default_model(mn, sig, dev, seed=0)  # same init on every rank (replicated parameters)
+        prec = _lib.BF16 if args.precision == "bf16" else _lib.F32
+        fdt = prec if args.feat_dtype == "auto" else (_lib.BF16 if args.feat_dtype == "bf16" else _lib.F32)
+        total_steps = 4000 * 1000  # train_hash2.py:156-157: epochs * len(loader) (1000 epochs x 4000 batches of the 64M lego rays)
+        tr = HashNeRFTrainer(enc, mlp, near=2.0, far=6.0, num_samples=S, total_steps=total_steps, precision=prec, feat_dtype=fdt,
+                             overlap_comm=os.environ.get("HBR_OVERLAP_COMM", "1") != "0")  # A/B switch for the staged all-reduce
+        torch.manual_seed(1234)  # identical jitter t[S] on every rank
 
-    def sync():
+        def sync():
+            if world > 1:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+        if args.only_dropin:
+            ms, dl = dropin_leg(dev, batches, mn, sig, S, args.steps, args.warmup, total_steps, args.precision)
+            print(json.dumps({"dropin_ms_per_step": ms, "dropin_value": R * S / (ms * 1e-3), "loss": dl, "steps": args.steps}), flush=True)
+            return
+        print(f"[bench] rank {rank}/{world}: model + {pool} batches resident, warming up", file=sys.stderr, flush=True)
+        for i in range(args.warmup):
+            tr.step(*batches[i % pool])
+        sync()
+        if not args.no_kernel_events:
+            tr.timers = {}
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            tr.step(*batches[i % pool])
+        sync()
+        dt = time.perf_counter() - t0
         if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+            dt = float(tmax.item())
+        print(f"[bench] timed {args.steps} steps in {dt:.3f}s", file=sys.stderr, flush=True)
+        loss = float(tr.last_loss.item())
+        samples = R * S * world * args.steps
+        value = samples / dt
 
-    if args.only_dropin:
-        ms, dl = dropin_leg(dev, batches, mn, sig, S, args.steps, args.warmup, total_steps, args.precision)
-        print(json.dumps({"dropin_ms_per_step": ms, "dropin_value": R * S / (ms * 1e-3), "loss": dl, "steps": args.steps}), flush=True)
-        return
-    print(f"[bench] rank {rank}/{world}: model + {pool} batches resident, warming up", file=sys.stderr, flush=True)
-    for i in range(args.warmup):
-        tr.step(*batches[i % pool])
-    sync()
-    if not args.no_kernel_events:
-        tr.timers = {}
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        tr.step(*batches[i % pool])
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tmax.item())
-    print(f"[bench] timed {args.steps} steps in {dt:.3f}s", file=sys.stderr, flush=True)
-    loss = float(tr.last_loss.item())
-    samples = R * S * world * args.steps
-    value = samples / dt
+        # ---- per-kernel durations from the HIP events recorded on the launch stream --------------------------
+        kern = {}
+        if tr.timers:
+            for name, evs in tr.timers.items():
+                kern[name] = sum(a.elapsed_time(b) for a, b in evs) / len(evs)  # ms
+        N = R * S
+        roofs = {}
+        fb = 2 if fdt == _lib.BF16 else 4  # bytes per stored feature / feature-gradient element
+        comm_ms = kern.pop("allreduce_exposed", None)  # world > 1: time the compute stream waits for the collective
+        if kern:
+            roofs["hash_fwd"] = dict(bound="hbm", achieved=hash_fwd_bytes(fb) * N / (kern["hash_fwd"] * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+            roofs["hash_bwd"] = dict(bound="hbm", achieved=hash_bwd_bytes(fb) * N / (kern["hash_bwd"] * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+            roofs["mlp_fwd"] = dict(bound="mfma", achieved=MLP_FWD_FLOP * N / (kern["mlp_fwd"] * 1e-3) / 1e12, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s")
+            roofs["mlp_bwd"] = dict(bound="mfma", achieved=MLP_BWD_FLOP * N / (kern["mlp_bwd"] * 1e-3) / 1e12, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s")
+            # Stored profile numbers (rocprofv3 --pmc passes cannot run inside this process): HBM bytes per launch and the
+            # issue-side counters, each labelled with the profile it came from so that a stale file cannot pass as live.
+            pmc, issue = {}, {}
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                    pmc = json.load(f)
+                with open(os.path.join(ROOT, "profiles", "pmc_issue.json")) as f:
+                    issue = json.load(f)
+            except Exception:
+                pass
+            # HBM bytes a launch cannot avoid at this size: K1 tables once + the feature write; K2 the feature-gradient read,
+            # the gradient-table write and the normalised coordinates (written once); K3/K4 their streams
+            compulsory = {"hash_fwd": 16 * 65536 * 8 + N * 32 * fb, "hash_bwd": N * 32 * fb + 16 * 65536 * 8 + N * 12,
+                          "mlp_fwd": N * 32 * fb + N * 16, "mlp_bwd": 2 * N * 32 * fb + 2 * N * 16}
+            for k, r in roofs.items():
+                r["frac"] = r["achieved"] / r["peak"]
+                r["kernel"] = k
+                r["avg_ms"] = kern[k]
+                same_shape = (R, S, fb) == (16000, 128, 2)  # the stored profiles are of the default configuration
+                r["traffic"] = pmc.get(k) if same_shape else None
+                r["traffic_source"] = pmc.get("source", "profiles/pmc_traffic.json") + " (stored rocprofv3 --pmc profile of this configuration, not measured in this run)" if r["traffic"] else None
+                if r["bound"] == "hbm":
+                    # `frac` prices SURVEY 8d's ALGORITHMIC bytes (every gathered / scattered table row counted as memory
+                    # traffic).  The tables live in the L2s, so this is not an HBM fraction and can exceed 1; the HBM
+                    # fraction proper and the resource that does bound the kernel follow.
+                    r["frac_basis"] = "algorithmic bytes (SURVEY 8d) / 8 TB/s - NOT HBM bytes: the hash tables are L2-resident"
+                    if r["traffic"]:
+                        r["hbm_frac"] = r["traffic"] / (kern[k] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                        r["traffic_vs_compulsory"] = r["traffic"] / compulsory[k]
+                    if r["frac"] > 1:
+                        r["frac_note"] = "above 1: the byte model is not a ceiling for a cache-resident table; see hbm_frac and roofline_issue"
+                if same_shape and k in issue:
+                    r["roofline_issue"] = issue[k]
+        dominant = max(kern, key=kern.get) if kern else None
 
-    # ---- per-kernel durations from the HIP events recorded on the launch stream --------------------------
-    kern = {}
-    if tr.timers:
-        for name, evs in tr.timers.items():
-            kern[name] = sum(a.elapsed_time(b) for a, b in evs) / len(evs)  # ms
-    N = R * S
-    roofs = {}
-    fb = 2 if fdt == _lib.BF16 else 4  # bytes per stored feature / feature-gradient element
-    if kern:
-        roofs["hash_fwd"] = dict(bound="hbm", achieved=hash_fwd_bytes(fb) * N / (kern["hash_fwd"] * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
-        roofs["hash_bwd"] = dict(bound="hbm", achieved=hash_bwd_bytes(fb) * N / (kern["hash_bwd"] * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
-        roofs["mlp_fwd"] = dict(bound="mfma", achieved=MLP_FWD_FLOP * N / (kern["mlp_fwd"] * 1e-3) / 1e12, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s")
-        roofs["mlp_bwd"] = dict(bound="mfma", achieved=MLP_BWD_FLOP * N / (kern["mlp_bwd"] * 1e-3) / 1e12, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s")
-        pmc = {}
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                pmc = json.load(f)
-        except Exception:
-            pass
-        for k, r in roofs.items():
-            r["frac"] = r["achieved"] / r["peak"]
-            r["kernel"] = k
-            r["avg_ms"] = kern[k]
-            r["traffic"] = pmc.get(k)  # HBM bytes per launch from rocprofv3 --pmc passes (profiles/), or null
-    dominant = max(kern, key=kern.get) if kern else None
+        # ---- the reference's own loop on the drop-in classes (the boundary north_star names), same batches ---------
+        dropin = None
+        if rank == 0 and world == 1 and not args.no_dropin:
+            ms, dl = dropin_leg(dev, batches, mn, sig, S, args.steps, args.warmup, total_steps, args.precision)
+            dropin = dict(ms_per_step=ms, value=R * S / (ms * 1e-3), loss=dl)
+            print(f"[bench] drop-in loop: {ms:.3f} ms/step", file=sys.stderr, flush=True)
 
-    # ---- the reference's own loop on the drop-in classes (the boundary north_star names), same batches ---------
-    dropin = None
-    if rank == 0 and world == 1 and not args.no_dropin:
-        ms, dl = dropin_leg(dev, batches, mn, sig, S, args.steps, args.warmup, total_steps, args.precision)
-        dropin = dict(ms_per_step=ms, value=R * S / (ms * 1e-3), loss=dl)
-        print(f"[bench] drop-in loop: {ms:.3f} ms/step", file=sys.stderr, flush=True)
+        # ---- CPU baseline: the oracle (a port of the reference's PyTorch-CPU path) on a bounded sample ---------
+        cpu = None
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(S, mn, sig, total_steps)
 
-    # ---- CPU baseline: the oracle (a port of the reference's PyTorch-CPU path) on a bounded sample ---------
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(S, mn, sig, total_steps)
+        line = None
+        if rank == 0:
+            line = {
+                "metric": "ray-samples/sec @128 samples/ray on lego (full train step: fwd+bwd+optimiser)",
+                "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+                "dtype": "bf16" if prec == _lib.BF16 else "f32", "data": "synthetic",
+                "config": {"workload": "lego-shaped synthetic scene, hash encoding L=16 F=2 T=2^16 N_min=16 N_max=2048, "
+                                       f"{R} rays/rank x {S} samples/ray ({scaling} scaling), MLP 32-64-64-16 / 39-64-64-3, fp32 tables, "
+                                       f"{'bf16' if prec == _lib.BF16 else 'fp32'} MLP (MFMA), "
+                                       f"{'bf16' if fdt == _lib.BF16 else 'fp32'} feature/feature-gradient buffers, Adam+AdamW+cosine",
+                           "rays_per_rank": R, "samples_per_ray": S, "global_rays": R * world, "levels": 16, "table_rows": 2 ** 16,
+                           "parallelism": f"ray-sharded dp{world}, 1 all-reduce/step" if world > 1 else "single GPU"},
+                "loss": loss,
+                "roofline": roofs.get(dominant), "roofline_hash_lookup": roofs.get("hash_fwd"), "kernels": roofs or None,
+                "cpu_baseline": cpu,
+                # multi-GPU diagnostics: the one all-reduce per step of the flat 8.05 MiB gradient buffer
+                "allreduce_exposed_ms": comm_ms, "overlap_comm": bool(tr.overlap_comm), "split_scatter": bool(tr.split_scatter),
+                "allreduce_bytes": int(tr.grad.numel() * 4) if world > 1 else 0,
+                "dist_backend": (torch.distributed.get_backend() if world > 1 else None),
+                # train_hash2.py:211-234 as written (vol_render + autograd + torch.optim), drop-in classes, same batches
+                "dropin_ms_per_step": dropin and dropin["ms_per_step"], "dropin_value": dropin and dropin["value"],
+            }
+            print(json.dumps(line), flush=True)
+        return line
 
-    if rank == 0:
-        line = {
-            "metric": "ray-samples/sec @128 samples/ray on lego (full train step: fwd+bwd+optimiser)",
-            "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "bf16" if prec == _lib.BF16 else "f32", "data": "synthetic",
-            "config": {"workload": "lego-shaped synthetic scene, hash encoding L=16 F=2 T=2^16 N_min=16 N_max=2048, "
-                                   f"{R} rays/rank x {S} samples/ray ({args.scaling} scaling), MLP 32-64-64-16 / 39-64-64-3, fp32 tables, "
-                                   f"{'bf16' if prec == _lib.BF16 else 'fp32'} MLP (MFMA), "
-                                   f"{'bf16' if fdt == _lib.BF16 else 'fp32'} feature/feature-gradient buffers, Adam+AdamW+cosine",
-                       "rays_per_rank": R, "samples_per_ray": S, "global_rays": R * world, "levels": 16, "table_rows": 2 ** 16,
-                       "parallelism": f"ray-sharded dp{world}, 1 all-reduce/step" if world > 1 else "single GPU"},
-            "loss": loss,
-            "roofline": roofs.get(dominant), "roofline_hash_lookup": roofs.get("hash_fwd"), "kernels": roofs or None,
-            "cpu_baseline": cpu,
-            # train_hash2.py:211-234 as written (vol_render + autograd + torch.optim), drop-in classes, same batches
-            "dropin_ms_per_step": dropin and dropin["ms_per_step"], "dropin_value": dropin and dropin["value"],
-        }
-        print(json.dumps(line), flush=True)
+    for sc in (("weak", "strong") if args.scaling == "both" else (args.scaling,)):
+        run(sc)
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -168,13 +168,13 @@ class HashNeRFTrainer:
                     red.launch(piece)
 
             self._timed("hash_bwd", scatter_halves)
-            red.finish()
+            self._timed("allreduce_exposed", red.finish) if self.world > 1 else red.finish()
         else:
             self._timed("hash_bwd", lambda: ops.hash_encode_bwd(g, dfeat, self.g_tab, rays=rays, layout=PLANAR, algo=self.scatter_algo,
                                                                 dy_absmax=amax, overwrite=True))
             # the one collective of the step
             if self.world > 1:
-                torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+                self._timed("allreduce_exposed", lambda: torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM, group=self.pg))
         # optimiser (dense Adam over every table row, as the reference's torch.optim.Adam does)
         k = self.step_count
         gs = 1.0 / self.world

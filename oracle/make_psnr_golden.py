@@ -65,13 +65,15 @@ def scene():
     return mn, sig, batches, test
 
 
-def run_seed(ref_dir: str, seed: int, steps: int, eval_every: int, out: str, threads: int):
+def run_seed(ref_dir: str, seed: int, steps: int, eval_every: int, out: str, threads: int, perturb_ulps: int = 0, save_final: str = ""):
     import make_golden as MG
     import ref_cpu
     torch.set_num_threads(threads)
     ref = MG.import_reference(ref_dir)
     mn, sig, batches, test = scene()
     tables0, u, params0 = seeded_inputs(seed, steps)
+    for _ in range(perturb_ulps):  # sensitivity study: every initial table entry moved to the next fp32 value (1 ulp ~ 1e-11)
+        tables0 = np.nextafter(tables0, np.float32(np.inf))
     enc = MG.build_encoder(ref, tables0, 2048.0, 16, mn.numpy(), float(sig))
     denc = ref.encoder.PositionalEncoder(3, 4)
     nerf = torch.nn.DataParallel(MG.build_mlp(ref, params0))          # train_hash2.py:127 (no GPU: calls the module)
@@ -104,7 +106,16 @@ def run_seed(ref_dir: str, seed: int, steps: int, eval_every: int, out: str, thr
             print(f"seed {seed} step {k + 1:5d} loss {losses[k]:.5f} held-out PSNR {p:.3f} dB ({time.time() - t0:.0f}s)", flush=True)
             np.savez(out, seed=seed, steps=steps, eval_steps=np.array(ev_steps), psnr=np.array(ev_psnr, dtype=np.float64),
                      loss=losses[:k + 1], input_checksum=checksum(tables0, u, *[v.numpy() for v in params0.values()]),
-                     scene_checksum=checksum(*[a.numpy() for b in batches[:2] for a in b], *[a.numpy() for a in test]))
+                     scene_checksum=checksum(*[a.numpy() for b in batches[:2] for a in b], *[a.numpy() for a in test]),
+                     perturb_ulps=perturb_ulps)
+    if save_final:  # the trained parameters + the reference's own render of the held-out rays with them
+        with torch.no_grad():
+            C, _, _ = MG.quiet(vr.vol_render, nerf, test[1], test[0], num_samples=S, t=t_eval, update_mask=False, dir_norm=test[2], hierarchical=False)
+        fin = {"tables": np.stack([enc.Embedding_list[l].weight.detach().numpy() for l in range(L)]), "Cr_eval": C.numpy(),
+               "psnr": float(ref.helper.calc_psnr(C, test[3])), "seed": seed, "steps": steps, "perturb_ulps": perturb_ulps}
+        for name, p_ in nerf.module.named_parameters():
+            fin["p." + name] = p_.detach().numpy()
+        np.savez_compressed(save_final, **fin)
 
 
 def merge(files):
@@ -136,9 +147,11 @@ if __name__ == "__main__":
     ap.add_argument("--eval-every", type=int, default=50)
     ap.add_argument("--threads", type=int, default=2)
     ap.add_argument("--out", default="/tmp/psnr_seed.npz")
+    ap.add_argument("--perturb-ulps", type=int, default=0)
+    ap.add_argument("--save-final", default="")
     ap.add_argument("--merge", nargs="+")
     a = ap.parse_args()
     if a.merge:
         merge(a.merge)
     else:
-        run_seed(a.ref, a.seed, a.steps, a.eval_every, a.out, a.threads)
+        run_seed(a.ref, a.seed, a.steps, a.eval_every, a.out, a.threads, a.perturb_ulps, a.save_final)

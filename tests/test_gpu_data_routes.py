@@ -20,14 +20,15 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])   # bf16: the BASELINE dtype (bf16 MLP, bf16 feature buffers)
 @pytest.mark.parametrize("fmt", ["blender", "colmap"])
-def test_train_script_on_a_scene_on_disk(tmp_path, monkeypatch, fmt):
+def test_train_script_on_a_scene_on_disk(tmp_path, monkeypatch, fmt, precision):
     from hbr_amd import train_hash2
     monkeypatch.chdir(tmp_path)
     root = os.path.join("data", "lego") if fmt == "blender" else "scene"   # train_hash2.py:51: default path = Blender lego
     views = write_nerf_scene(root, fmt, n_views=6, H=32, W=32, seed=3)
     argv = ["--num_batch", "1024", "--num_samples", "64", "--hash_size", "12", "--num_epochs", "40", "--steps", "160",
-            "--write", "--model_name", "m", "--out_dir", str(tmp_path / "res"), "--precision", "fp32"]
+            "--write", "--model_name", "m", "--out_dir", str(tmp_path / "res"), "--precision", precision]
     if fmt == "colmap":
         argv += ["--data_path", root + "/"]
     r = train_hash2.main(argv)
@@ -74,3 +75,41 @@ def test_nerf2mesh_entry_point(tmp_path, monkeypatch):
     pe = ref_cpu.dir_encode(torch.tensor([[0.0, 0.0, 1.0]]), 4).half().float().expand(sel.numel(), 24)
     want = ref_cpu.mlp_forward(feat, pe, prm).numpy()
     assert np.allclose(grid.reshape(-1, 4)[sel.numpy()], want, rtol=1e-4, atol=1e-5)
+
+
+def test_grid_query_256_cubed():
+    """BASELINE config 5's query at a real resolution: 256^3 = 16.8 M lattice points through K1 + K3 (nerf2mesh.py:26-88):
+    shape, finiteness, the oracle on a 1-in-4096 subsample, and the time of a second (warm) call."""
+    import time
+    from hbr_amd import synthetic
+    from hbr_amd.grid_query import grid_coordinates, query_density_grid
+    from hbr_amd.trainer import HashNeRFTrainer, build_default_model
+    o, d, dn, gt = (a.to(DEV) for a in synthetic.scene_rays(4096, seed=5))
+    mn, mx, sig = synthetic.ray_bbox(o.cpu(), d.cpu())
+    enc, denc, mlp = build_default_model(mn, sig, DEV, T=2 ** 14, seed=1)
+    tr = HashNeRFTrainer(enc, mlp, num_samples=64, total_steps=200)
+    for _ in range(60):   # a field that is not the untrained constant
+        tr.step(o, d, dn.reshape(-1), gt)
+    res = 256
+    lo, hi = torch.tensor([-1.2, -1.2, -1.2]), torch.tensor([1.2, 1.2, 1.2])
+    grid = query_density_grid(enc, mlp, lo, hi, res)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    grid2 = query_density_grid(enc, mlp, lo, hi, res)
+    torch.cuda.synchronize()
+    warm = time.perf_counter() - t0
+    assert grid.shape == (res, res, res, 4) and grid.dtype == torch.float32
+    assert bool(torch.isfinite(grid).all()) and torch.equal(grid, grid2)
+    assert float(grid[..., 3].max()) > 1.0 and float((grid[..., 3] > 0.5).float().mean()) > 1e-3   # the solid is there
+    assert warm < 2.0, warm   # 16.8 M points: tens of milliseconds of kernels; a generous bound against a silent slow path
+    # oracle on a subsample of the lattice (same fp16-rounded coordinates, direction (0, 0, 1) as nerf2mesh.py:69-70)
+    pts = grid_coordinates(lo, hi, res, "cpu")
+    sel = torch.arange(0, res ** 3, 4096)
+    tabs = [lv.weight.detach().cpu() for lv in enc.Embedding_list]
+    prm = {f"{s}.{i}.{k}": getattr(getattr(mlp, s)[i], k).detach().cpu() for s in ("sig_model", "col_model") for i in (0, 2, 4)
+           for k in ("weight", "bias")}
+    feat = ref_cpu.hash_encode(pts[sel], tabs, ref_cpu.level_scales(16, 2048.0, 16), mn, sig)
+    pe = ref_cpu.dir_encode(torch.tensor([[0.0, 0.0, 1.0]]), 4).half().float().expand(sel.numel(), 24)
+    want = ref_cpu.mlp_forward(feat, pe, prm).numpy()
+    got = grid.reshape(-1, 4)[sel.to(DEV)].cpu().numpy()
+    assert np.allclose(got, want, rtol=1e-4, atol=2e-5), float(np.abs(got - want).max())

@@ -9,12 +9,14 @@ properties the round-2 scatter kernel adds.
 * K4 as shipped: planar bf16 features in, bf16 MFMA, bf16 feature gradient out, against the oracle under torch's bf16
   autocast on the same bf16-rounded features (reference test_hash.py:52-72 under train_hash2.py:218).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
 
 import ref_cpu
-from conftest import load_golden
+from conftest import ROOT, load_golden
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -542,3 +544,38 @@ def test_overwrite_mode_equals_accumulating_into_zeros(ops):
     got = torch.ones_like(P)
     ops.mlp_bwd(feat[:, :0].contiguous(), PLANAR, pe[:0], 1, P, BF16, dout[:0], got, overwrite=True)
     assert float(got.abs().max()) == 0.0
+
+
+def test_integration_md_ctypes_stub_runs_verbatim():
+    """INTEGRATION.md section B - the reference-side ctypes binding a maintainer would add next to hash_encoding.py - is
+    executed AS PRINTED (only the library path is filled in) on an object with the reference HashEncoder's attributes
+    (hash_encoding.py:6-39: L, T, F, N_min, b, mu, sigma, Embedding_list), forward and backward, against the oracle."""
+    import re
+    import types
+    import hbr_amd._lib as L
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = text[text.index("## B."):]
+    code = re.search(r"```python\n(.*?)```", sec, re.S).group(1)
+    assert "/path/to/libhbr_hip.so" in code and "class _HashEncode" in code
+    ns = {}
+    exec(compile(code.replace("/path/to/libhbr_hip.so", L.LIB_PATH), "INTEGRATION.md#B", "exec"), ns)
+    Lv, T, F, N = 16, 2 ** 12, 2, 3000
+    rng = np.random.default_rng(12)
+    mu, sigma = torch.tensor([-1.0, -0.7, 0.1]), torch.tensor(2.9)
+    enc = types.SimpleNamespace(L=Lv, T=T, F=F, N_min=torch.tensor(16), mu=mu.to(DEV), sigma=sigma.to(DEV))
+    enc.b = torch.exp((torch.log(torch.tensor(2048.0)) - torch.log(enc.N_min)) / (Lv - 1))     # hash_encoding.py:13
+    tabs = [torch.from_numpy(rng.uniform(-0.5, 0.5, (T, F)).astype(np.float32)) for _ in range(Lv)]
+    weights = [t.clone().to(DEV).requires_grad_(True) for t in tabs]
+    x = mu + torch.from_numpy(rng.uniform(0.01, 2.0, (N, 3)).astype(np.float32))
+    y = ns["_HashEncode"].apply(x.to(DEV), enc, *weights)
+    dy = torch.from_numpy(rng.normal(0, 1, (N, Lv * F)).astype(np.float32))
+    y.backward(dy.to(DEV))
+    sc = ref_cpu.level_scales(16, 2048.0, Lv)
+    ref_t = [t.clone().requires_grad_(True) for t in tabs]
+    y_ref = ref_cpu.hash_encode(x, ref_t, sc, mu, sigma)
+    y_ref.backward(dy)
+    assert float((y.detach().cpu() - y_ref.detach()).abs().max()) <= 1e-6 * float(y_ref.abs().max())
+    for l in range(Lv):
+        g, gr = weights[l].grad.cpu(), ref_t[l].grad
+        assert float((g - gr).abs().max()) <= 1e-4 * float(gr.abs().max()) + 1e-9, l
+

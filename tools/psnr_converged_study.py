@@ -1,0 +1,75 @@
+"""Held-out PSNR at the horizon of tests/golden/g15_converged_psnr.npz (the reference's own modules, trained to a plateau):
+every HIP route / precision from the same seeded inputs.  Prints one row per (seed, configuration)."""
+import os, sys
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import make_psnr_golden as MP, ref_cpu
+from hbr_amd._lib import BF16, F32
+from hbr_amd.helper import calc_psnr
+from hbr_amd.trainer import HashNeRFTrainer, build_default_model
+from hbr_amd.vol_renderer import Volume_Renderer
+DEV = "cuda:0"
+g = dict(np.load(os.path.join(ROOT, "tests", "golden", "g15_converged_psnr.npz")))
+steps, ev = int(g["steps"]), [int(v) for v in g["eval_steps"]]
+mn, sig, batches, test = MP.scene()
+batches = [tuple(a.to(DEV) for a in b) for b in batches]
+test = tuple(a.to(DEV) for a in test)
+t_eval = torch.linspace(MP.NEAR, MP.FAR, MP.S, device=DEV)
+seeds = [int(s) for s in os.environ.get("SEEDS", ",".join(str(int(s)) for s in g["seeds"])).split(",")]
+configs = os.environ.get("CONFIGS", "fused-bf16,fused-bf16-f32feat,fused-fp32,dropin-bf16,dropin-fp32").split(",")
+
+
+def model(tables0, params0):
+    enc, denc, mlp = build_default_model(mn, sig, DEV, L=MP.L, T=MP.T, seed=0)
+    with torch.no_grad():
+        for l in range(MP.L): enc.Embedding_list[l].weight.copy_(torch.from_numpy(tables0[l]))
+        for k, v in params0.items():
+            seq, idx, kind = k.split("."); getattr(getattr(mlp, seq)[int(idx)], kind).copy_(v)
+    return enc, denc, mlp
+
+
+def run(seed, cfg):
+    tables0, u, params0 = MP.seeded_inputs(seed, steps)
+    ts = torch.stack([ref_cpu.strat_jitter_to_t(MP.NEAR, MP.FAR, MP.S, torch.from_numpy(u[k])) for k in range(steps)]).to(DEV)
+    enc, denc, mlp = model(tables0, params0)
+    curve = []
+    if cfg.startswith("fused"):
+        prec = F32 if "fp32" in cfg else BF16
+        tr = HashNeRFTrainer(enc, mlp, near=MP.NEAR, far=MP.FAR, num_samples=MP.S, total_steps=steps, precision=prec,
+                             feat_dtype=F32 if "f32feat" in cfg else None)
+        for k in range(steps):
+            tr.step(*batches[k % MP.NB], t=ts[k])
+            if k + 1 in ev:
+                curve.append(float(calc_psnr(tr.render(test[0], test[1], test[2], t=t_eval), test[3])))
+    else:
+        ac = "bf16" in cfg
+        nerf = torch.nn.DataParallel(mlp, device_ids=[0])
+        vr = Volume_Renderer(H=8, W=8, K=torch.eye(3), near=MP.NEAR, far=MP.FAR, device=DEV, Pos_encode=enc, Dir_encode=denc,
+                             max_dim=2 ** 10, sigma_val=sig.to(DEV), mu=mn.to(DEV))
+        oe = torch.optim.Adam(enc.Embedding_list.parameters(), lr=0.05); om = torch.optim.AdamW(nerf.parameters(), lr=0.005)
+        se = torch.optim.lr_scheduler.CosineAnnealingLR(oe, T_max=steps, eta_min=1e-4); sm = torch.optim.lr_scheduler.CosineAnnealingLR(om, T_max=steps, eta_min=1e-4)
+        crit = torch.nn.MSELoss()
+        for k in range(steps):
+            o, d, dn, gt = batches[k % MP.NB]
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=ac):
+                Cr, Cf, _ = vr.vol_render(nerf, d, o, num_samples=MP.S, t=ts[k], update_mask=False, dir_norm=dn, hierarchical=False)
+                loss = crit(Cr, gt) + crit(Cf, gt)
+            loss.backward(); oe.step(); om.step(); se.step(); sm.step(); om.zero_grad(set_to_none=True); oe.zero_grad(set_to_none=True)
+            if k + 1 in ev:
+                with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=ac):
+                    C = vr.vol_render(nerf, test[1], test[0], num_samples=MP.S, t=t_eval, update_mask=False, dir_norm=test[2], hierarchical=False)[0]
+                curve.append(float(calc_psnr(C, test[3])))
+    return np.array(curve)
+
+
+for cfg in configs:
+    ds = []
+    for i, seed in enumerate(int(s) for s in g["seeds"]):
+        if seed not in seeds: continue
+        c = run(seed, cfg); ref = g["psnr"][i]
+        q = len(ev) // 4
+        ds.append(c[-1] - ref[-1])
+        print(f"{cfg:20s} seed {seed}: ref {ref[-1]:.3f}  hip {c[-1]:.3f}  delta {ds[-1]:+.3f} | step {ev[q]}: {c[q]-ref[q]:+.3f}  step {ev[2*q]}: {c[2*q]-ref[2*q]:+.3f}  step {ev[3*q]}: {c[3*q]-ref[3*q]:+.3f} | tail span {c[int(len(c)*.8):].max()-c[int(len(c)*.8):].min():.3f}", flush=True)
+    ds = np.array(ds)
+    print(f"{cfg:20s} mean delta {ds.mean():+.3f}  std {ds.std():.3f}  max|d| {np.abs(ds).max():.3f}", flush=True)
