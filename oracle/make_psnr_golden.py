@@ -18,9 +18,11 @@ Workload (small enough for the CPU, large enough that the GPU test runs the SHIP
 L=16, F=2, T=2^12, N_min=16, N_max=2048.0; tables U(-1e-4,1e-4) and nn.Linear-style MLP weights from numpy PCG64(seed).
 The cosine schedule ends at the horizon, so the run anneals into a plateau.
 
-Usage (one process per seed, then merge):
-    PYTHONDONTWRITEBYTECODE=1 python oracle/make_psnr_golden.py --seed 1 --steps 2000 --out /tmp/psnr_s1.npz
-    python oracle/make_psnr_golden.py --merge /tmp/psnr_s1.npz /tmp/psnr_s2.npz ...   -> tests/golden/g15_converged_psnr.npz
+Usage (one process per seed, ~50 min each on one thread, then merge):
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_psnr_golden.py --seed 1 --steps 2000 --out /tmp/psnr/s1.npz
+    ... --seed 1 --perturb-ulps 1 --save-final /tmp/psnr_p/final_s1.npz --out /tmp/psnr_p/s1.npz      (sensitivity re-run)
+    python oracle/make_psnr_golden.py --merge /tmp/psnr/s*.npz --merge-ulp /tmp/psnr_p/s?.npz    -> tests/golden/g15_converged_psnr.npz
+    cp /tmp/psnr_p/final_s1.npz tests/golden/g15b_trained_weights.npz    (the reference's trained weights + its held-out render)
 """
 from __future__ import annotations
 
@@ -118,8 +120,16 @@ def run_seed(ref_dir: str, seed: int, steps: int, eval_every: int, out: str, thr
         np.savez_compressed(save_final, **fin)
 
 
-def merge(files):
+def merge(files, ulp_files=()):
+    """files: the unperturbed runs (one per seed); ulp_files: the same seeds re-run with --perturb-ulps 1 (the reference's
+    own sensitivity to a one-ulp change of its initial tables, stored as psnr_ulp)."""
     runs = sorted((np.load(f) for f in files), key=lambda z: int(z["seed"]))
+    ulps = sorted((np.load(f) for f in ulp_files), key=lambda z: int(z["seed"]))
+    extra = {}
+    if ulps:
+        assert [int(z["seed"]) for z in ulps] == [int(z["seed"]) for z in runs] and all(int(z["perturb_ulps"]) == 1 for z in ulps)
+        assert all(int(z["eval_steps"][-1]) == int(z["steps"]) for z in ulps), "a perturbed run did not finish"
+        extra["psnr_ulp"] = np.stack([z["psnr"] for z in ulps])
     steps = {int(z["steps"]) for z in runs}
     assert len(steps) == 1, "all seeds must share the horizon"
     ev = runs[0]["eval_steps"]
@@ -130,12 +140,13 @@ def merge(files):
              loss_tail=np.stack([z["loss"][-64:] for z in runs]),
              input_checksum=np.array([float(z["input_checksum"]) for z in runs]),
              scene_checksum=float(runs[0]["scene_checksum"]),
-             config=np.array([R, S, L, T, NB, EVAL_RAYS, EVAL_SEED, BATCH_SEED0, BBOX_SEED]))
+             config=np.array([R, S, L, T, NB, EVAL_RAYS, EVAL_SEED, BATCH_SEED0, BBOX_SEED]), **extra)
     z = np.load(OUT)
-    for s, p in zip(z["seeds"], z["psnr"]):
+    for i, (s, p) in enumerate(zip(z["seeds"], z["psnr"])):
         n = len(p)
         tail = p[int(n * 0.8):]
-        print(f"seed {s}: final {p[-1]:.3f} dB; last 20% of the horizon spans {tail.max() - tail.min():.3f} dB")
+        more = f"; with 1-ulp-moved tables {z['psnr_ulp'][i][-1]:.3f} dB ({z['psnr_ulp'][i][-1] - p[-1]:+.3f})" if "psnr_ulp" in z.files else ""
+        print(f"seed {s}: final {p[-1]:.3f} dB; last 20% of the horizon spans {tail.max() - tail.min():.3f} dB{more}")
     print("wrote", OUT)
 
 
@@ -150,8 +161,9 @@ if __name__ == "__main__":
     ap.add_argument("--perturb-ulps", type=int, default=0)
     ap.add_argument("--save-final", default="")
     ap.add_argument("--merge", nargs="+")
+    ap.add_argument("--merge-ulp", nargs="*", default=[])
     a = ap.parse_args()
     if a.merge:
-        merge(a.merge)
+        merge(a.merge, a.merge_ulp)
     else:
         run_seed(a.ref, a.seed, a.steps, a.eval_every, a.out, a.threads, a.perturb_ulps, a.save_final)

@@ -277,3 +277,33 @@ def test_update_grid_vs_reference(golden):
         assert np.array_equal(grid.numpy(), g[f"grid{k}"]), k
         assert np.array_equal(tmp.numpy(), g[f"tmp{k}"]), k
     assert (g["tmp0"] < 0).sum() > 10 and g["grid2"].all() and 0 < g["grid0"].sum() < g["grid1"].sum() < G ** 3
+
+
+def test_oracle_on_the_references_trained_model_and_first_steps(golden):
+    """G15 / G15b (oracle/make_psnr_golden.py: the reference's own modules trained for 2000 steps): the oracle renders the
+    reference's trained weights to the reference's own held-out colours and PSNR, and its train step reproduces the
+    first losses of the reference's loop (train_hash2.py:211-234) from the same seeded inputs."""
+    import make_psnr_golden as MP
+    g, gw = golden("g15_converged_psnr.npz"), golden("g15b_trained_weights.npz")
+    mn, sig, batches, test = MP.scene()
+    sc = ref_cpu.level_scales(16, 2048.0, MP.L)
+    tabs = [torch.from_numpy(gw["tables"][l]) for l in range(MP.L)]
+    prm = {k[2:]: torch.from_numpy(v) for k, v in gw.items() if k.startswith("p.")}
+    t_eval = torch.linspace(MP.NEAR, MP.FAR, MP.S)
+    with torch.no_grad():
+        C, _, _ = ref_cpu.render(test[0][:512], test[1][:512], t_eval, test[2][:512], tabs, sc, mn, sig, prm)
+    assert np.allclose(C.numpy(), gw["Cr_eval"][:512], rtol=1e-4, atol=1e-5)
+    assert abs(float(ref_cpu.psnr(torch.from_numpy(gw["Cr_eval"]), test[3])) - float(gw["psnr"])) < 1e-3
+    # first steps of seed g["seeds"][0]
+    seed, steps = int(g["seeds"][0]), int(g["steps"])
+    tables0, u, params0 = MP.seeded_inputs(seed, steps)
+    assert abs(MP.checksum(tables0, u, *[v.numpy() for v in params0.values()]) - float(g["input_checksum"][0])) < 1e-6 * float(g["input_checksum"][0])
+    tt = [torch.from_numpy(tables0[l]).clone().requires_grad_(True) for l in range(MP.L)]
+    pp = {k: v.clone().requires_grad_(True) for k, v in params0.items()}
+    opts = ref_cpu.make_optimizers(tt, pp.values(), steps)
+    for k in range(3):
+        t = ref_cpu.strat_jitter_to_t(MP.NEAR, MP.FAR, MP.S, torch.from_numpy(u[k]))
+        loss = ref_cpu.train_step(batches[k % MP.NB], t, tt, sc, mn, sig, pp, opts)
+        assert abs(float(loss) - float(g["loss_head"][0][k])) <= 2e-4 * float(g["loss_head"][0][k]), (k, float(loss), float(g["loss_head"][0][k]))
+    ulp = g["psnr_ulp"][:, -1] - g["psnr"][:, -1]
+    assert g["psnr"].shape == g["psnr_ulp"].shape == (5, 40) and 0.1 < np.abs(ulp).max() < 2.0  # the metric's own noise floor

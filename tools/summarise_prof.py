@@ -1,6 +1,7 @@
 """Turn gpurun_out/<tag>/ (written by tools/profile_round.sh) into the files committed under profiles/:
-<tag>_kernel_stats.csv (rocprofv3 --stats summary, our kernels + the largest others), <tag>_pmc_hbm.csv,
-<tag>_bench.json, and profiles/pmc_traffic.json (read by bench.py for roofline.traffic).
+<tag>_kernel_stats.csv and <tag>_dropin_kernel_stats.csv (rocprofv3 --stats summaries), <tag>_pmc_hbm.csv,
+<tag>_issue_counters.csv, <tag>_bench.json, and profiles/pmc_traffic.json + profiles/pmc_issue.json (read by bench.py
+for roofline.traffic / roofline_issue, each carrying the tag it came from).
 HBM bytes per launch = (FETCH_SIZE*2 + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md, gfx950 correction)."""
 import csv, glob, json, os, sys
 from collections import defaultdict
@@ -14,29 +15,46 @@ dst = os.path.join(root, "profiles")
 KERNELS = {"hash_fwd": ["hash_fwd_kernel"],
            "hash_bwd": ["normalise_kernel", "absmax_", "meta_reduce_kernel", "hash_scatter_kernel", "dense_scatter_kernel",
                         "slab_reduce_kernel"],
-           "mlp_fwd": ["mlp_fwd_kernel"], "mlp_bwd": ["mlp_bwd_fused_kernel", "mlp_dw_reduce_kernel"]}
+           "mlp_fwd": ["mlp_fwd_kernel"], "mlp_bwd": ["mlp_bwd_fused_kernel", "mlp_dw_reduce_kernel", "mlp_dw_finalize_kernel"]}
 
-stats = glob.glob(os.path.join(src, "kt", "**", "*kernel_stats.csv"), recursive=True)[0]
-rows = list(csv.reader(open(stats)))
-with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
-    w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
-    w.writerow(rows[0])
-    for r in rows[1:]:
-        if len(r[0]) < 400:  # drop torch's page-long template names (random fill etc.), all < 0.3 % of the time
-            w.writerow(r)
 
-def counter(name):
-    """span -> kernel pattern -> list of per-launch counter values"""
-    f = glob.glob(os.path.join(src, name, "**", "*counter_collection.csv"), recursive=True)[0]
-    acc = defaultdict(lambda: defaultdict(list))
-    for r in csv.DictReader(open(f)):
-        for k, pats in KERNELS.items():
-            for pat in pats:
-                if pat in r["Kernel_Name"]:
-                    acc[k][pat].append(float(r["Counter_Value"]))
+def copy_stats(sub, name):
+    found = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
+    if not found:
+        return {}
+    rows = list(csv.reader(open(found[0])))
+    with open(os.path.join(dst, name), "w", newline="") as f:
+        w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
+        w.writerow(rows[0])
+        for r in rows[1:]:
+            if len(r[0]) < 400:  # drop torch's page-long template names (random fill etc.), all < 0.3 % of the time
+                w.writerow(r)
+    return {r["Name"]: float(r["AverageNs"]) for r in csv.DictReader(open(found[0]))}
+
+
+avg_ns = copy_stats("kt", f"{tag}_kernel_stats.csv")
+copy_stats("kt_dropin", f"{tag}_dropin_kernel_stats.csv")
+
+
+def counters(sub):
+    """counter name -> span -> kernel pattern -> list of per-launch values"""
+    acc = defaultdict(lambda: defaultdict(lambda: defaultdict(list)))
+    for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            for k, pats in KERNELS.items():
+                for pat in pats:
+                    if pat in r["Kernel_Name"]:
+                        acc[r["Counter_Name"]][k][pat].append(float(r["Counter_Value"]))
     return acc
 
-fetch, write = counter("fetch"), counter("write")
+
+allc = defaultdict(lambda: defaultdict(lambda: defaultdict(list)))
+for sub in sorted(glob.glob(os.path.join(src, "pmc*"))):
+    if os.path.isdir(sub):
+        for c, v in counters(os.path.basename(sub)).items():
+            allc[c] = v
+mean = lambda xs: sum(xs) / len(xs) if xs else 0.0
+fetch, write = allc["FETCH_SIZE"], allc["WRITE_SIZE"]
 traffic = {}
 with open(os.path.join(dst, f"{tag}_pmc_hbm.csv"), "w") as f:
     f.write("span,kernel,launches,FETCH_SIZE_KiB_avg,WRITE_SIZE_KiB_avg,hbm_bytes_per_launch=(FETCHx2+WRITE)*1024\n")
@@ -45,21 +63,73 @@ with open(os.path.join(dst, f"{tag}_pmc_hbm.csv"), "w") as f:
         for pat in pats:
             if not fetch[k][pat]:
                 continue
-            fa, wa = sum(fetch[k][pat]) / len(fetch[k][pat]), sum(write[k][pat]) / len(write[k][pat])
+            fa, wa = mean(fetch[k][pat]), mean(write[k][pat])
             tot += (2 * fa + wa) * 1024
             f.write(f"{k},{pat},{len(fetch[k][pat])},{fa:.1f},{wa:.1f},{(2 * fa + wa) * 1024:.0f}\n")
         traffic[k] = tot
         f.write(f"{k},TOTAL,,,,{tot:.0f}\n")
+traffic["source"] = f"profiles/{tag}_pmc_hbm.csv"
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+
+# ---- issue-side: what bounds the two hash kernels (neither is HBM-bound: VERDICT r2 weak #2) -------------------------
+# clock: GRBM_GUI_ACTIVE is summed over the 8 XCDs -> cycles = value / 8; duration from the kernel-trace stats
+def kernel_ns(pat):
+    for name, ns in avg_ns.items():
+        if pat in name and ("<true, 1, 1>" in name or "<" not in pat):
+            return ns
+    for name, ns in avg_ns.items():
+        if pat in name:
+            return ns
+    return 0.0
+
+
+issue = {}
+with open(os.path.join(dst, f"{tag}_issue_counters.csv"), "w") as f:
+    f.write("span,kernel,counter,avg_per_launch,launches\n")
+    for c in sorted(allc):
+        if c in ("FETCH_SIZE", "WRITE_SIZE"):
+            continue
+        for k in KERNELS:
+            for pat, v in allc[c][k].items():
+                f.write(f"{k},{pat},{c},{mean(v):.6g},{len(v)}\n")
+for span, pat in (("hash_bwd", "hash_scatter_kernel"), ("hash_fwd", "hash_fwd_kernel"), ("mlp_bwd", "mlp_bwd_fused_kernel"), ("mlp_fwd", "mlp_fwd_kernel")):
+    ns = kernel_ns(pat)
+    gui = mean(allc["GRBM_GUI_ACTIVE"][span][pat])
+    valu = mean(allc["SQ_INSTS_VALU"][span][pat])
+    if not ns or not gui:
+        continue
+    cycles = gui / 8.0
+    rec = {"kernel": pat, "avg_us": ns / 1e3, "clock_ghz": cycles / ns, "source": f"profiles/{tag}_issue_counters.csv + {tag}_kernel_stats.csv"}
+    if valu:
+        # one wave-instruction occupies its SIMD's VALU issue for 4 cycles (wave64 on SIMD-16 lanes x 4); 1024 SIMDs
+        rec.update(bound="valu-issue", valu_insts=valu, frac=valu * 4.0 / 1024.0 / cycles,
+                   note="SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / kernel cycles (fp64 and 32-bit integer multiplies take longer than 4: a lower bound on VALU-pipe occupancy)")
+    tcp = mean(allc["TCP_TOTAL_CACHE_ACCESSES_sum"][span][pat])
+    if span == "hash_fwd" and tcp:
+        rec.update(bound="l1-tag-rate", l1_line_lookups=tcp, lines_per_clk_per_cu=tcp / 256.0 / cycles, frac=min(1.0, tcp / 256.0 / cycles / 1.2),
+                   note="TCP_TOTAL_CACHE_ACCESSES / 256 CUs / kernel cycles; frac = that rate / 1.2, the highest this access pattern has sustained on the chip (an observed ceiling, not a datasheet number)")
+    mf = mean(allc["SQ_VALU_MFMA_BUSY_CYCLES"][span][pat])
+    if span.startswith("mlp") and mf:
+        rec.update(bound="mfma-pipe", mfma_busy_cycles=mf, frac=mf / 1024.0 / cycles,
+                   note="SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / kernel cycles")
+    issue[span] = rec
+issue["source"] = f"profiles/{tag}_issue_counters.csv"
+json.dump(issue, open(os.path.join(dst, "pmc_issue.json"), "w"), indent=1)
+
 line = [l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")][-1]
-# the bench line was printed before this round's PMC passes existed: its `traffic` fields (read from the previous
-# pmc_traffic.json) are refreshed with the numbers just collected, everything else is kept as printed
+# the bench line was printed before this round's PMC passes existed: its `traffic` / `roofline_issue` fields (read from
+# the previous json files) are refreshed with the numbers just collected, everything else is kept as printed
 rec = json.loads(line)
-for key in ("roofline", "roofline_hash_lookup"):
-    if rec.get(key) and rec[key].get("kernel") in traffic:
-        rec[key]["traffic"] = traffic[rec[key]["kernel"]]
-for k, r in (rec.get("kernels") or {}).items():
-    if k in traffic:
+blocks = [rec.get("roofline"), rec.get("roofline_hash_lookup")] + list((rec.get("kernels") or {}).values())
+for r in blocks:
+    if r and r.get("kernel") in traffic:
+        k = r["kernel"]
         r["traffic"] = traffic[k]
+        r["traffic_source"] = traffic["source"] + " (stored rocprofv3 --pmc profile of this configuration, not measured in this run)"
+        if r.get("bound") == "hbm":
+            r["hbm_frac"] = traffic[k] / (r["avg_ms"] * 1e-3) / 1e9 / 8000.0
+        if k in issue:
+            r["roofline_issue"] = issue[k]
 open(os.path.join(dst, f"{tag}_bench.json"), "w").write(json.dumps(rec) + "\n")
 print(open(os.path.join(dst, f"{tag}_pmc_hbm.csv")).read())
+print(json.dumps(issue, indent=1))
