@@ -105,9 +105,16 @@ for span, pat in (("hash_bwd", "hash_scatter_kernel"), ("hash_fwd", "hash_fwd_ke
         rec.update(bound="valu-issue", valu_insts=valu, frac=valu * 4.0 / 1024.0 / cycles,
                    note="SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / kernel cycles (fp64 and 32-bit integer multiplies take longer than 4: a lower bound on VALU-pipe occupancy)")
     tcp = mean(allc["TCP_TOTAL_CACHE_ACCESSES_sum"][span][pat])
+    fills = mean(allc["TCP_TCC_READ_REQ_sum"][span][pat])
     if span == "hash_fwd" and tcp:
-        rec.update(bound="l1-tag-rate", l1_line_lookups=tcp, lines_per_clk_per_cu=tcp / 256.0 / cycles, frac=min(1.0, tcp / 256.0 / cycles / 1.2),
-                   note="TCP_TOTAL_CACHE_ACCESSES / 256 CUs / kernel cycles; frac = that rate / 1.2, the highest this access pattern has sustained on the chip (an observed ceiling, not a datasheet number)")
+        # Two candidate limits of a random 8-byte gather, both reported: L1 tag look-ups per clock per CU, and the L1 -> L2
+        # line fills against the ~34.5 TB/s aggregate L2 bandwidth (MI355X_MICROARCH.md) at 128 B per fill.  The
+        # two-lanes-per-point experiment (profiles/r03_k1_pair_lanes_experiment.txt) cut the look-ups by 24 % without
+        # changing the time, the fills did not move: the fills are the binding one.
+        l2_tbs = fills * 128.0 / (ns * 1e-9) / 1e12
+        rec.update(bound="l2-line-fills", l1_line_lookups=tcp, lines_per_clk_per_cu=tcp / 256.0 / cycles, l1_to_l2_fills=fills,
+                   l2_fill_tb_per_s=l2_tbs, frac=l2_tbs / 34.5,
+                   note="TCP_TCC_READ_REQ x 128 B / kernel time / 34.5 TB/s aggregate L2 bandwidth; also given: TCP_TOTAL_CACHE_ACCESSES / 256 CUs / kernel cycles (L1 tag look-ups per clock per CU)")
     mf = mean(allc["SQ_VALU_MFMA_BUSY_CYCLES"][span][pat])
     if span.startswith("mlp") and mf:
         rec.update(bound="mfma-pipe", mfma_busy_cycles=mf, frac=mf / 1024.0 / cycles,
