@@ -235,6 +235,8 @@ def render_prologue(device, precision: int, params: Optional[torch.Tensor] = Non
         R = rays_d.shape[0]
         pe = torch.empty((R, 24), dtype=torch.float32, device=device)
     ws = _mlp_ws(precision, device) if params is not None else None
+    if t is None and pe is None and ws is None:
+        return None, None
     require_gpu(t if t is not None else (pe if pe is not None else ws))
     check(lib().hbr_render_prologue(float(tn), float(tf), int(S), _ptr(u), int(seed) & (2 ** 64 - 1), int(off) & (2 ** 64 - 1), _ptr(t),
                                     _ptr(rays_d) if R else None, R, _ptr(pe) if R else None, _ptr(params), precision, _ptr(ws),

@@ -22,7 +22,9 @@ for h in range(2):
     feat = ops.hash_encode_fwd(geom, tables, rays=(o, d, t), layout=PLANAR, dtype=BF16)
     dout = torch.randn((N, 4), device=dev) * 1e-4
     halves.append(dict(rays=(o, d, t), pe=pe, feat=feat, dout=dout))
-sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+# HBR_PROBE_PRIO=1: the K1 stream gets the higher priority (its workgroups are taken first whenever a CU has room)
+sa = torch.cuda.Stream()
+sb = torch.cuda.Stream(priority=-1) if os.environ.get("HBR_PROBE_PRIO") else torch.cuda.Stream()
 g_mlp = torch.zeros_like(flat)
 g_tab = torch.zeros_like(tables)
 amax = torch.zeros(16, device=dev)
