@@ -89,13 +89,16 @@ def cpu_baseline(S, mn, sig, total_steps, Rc=4096, budget_s=25.0):
     return out
 
 
-def dropin_leg(dev, batches, mn, sig, S, steps, warmup, total_steps, precision):
+def dropin_leg(dev, batches, mn, sig, S, steps, warmup, total_steps, precision, optim=None):
     """The boundary BASELINE.json's north_star names: the loop body of /root/reference/train_hash2.py:211-234 written
     against the drop-in classes - Volume_Renderer.vol_render under autocast, MSE(Cr)+MSE(Cf), loss.backward(),
     torch.optim.Adam(lr .05) on encoder.Embedding_list / AdamW(lr .005) on DataParallel(MLP_3D), two
     CosineAnnealingLR, zero_grad(set_to_none=True) - on the same resident 16 000-ray batches as the fused step.
-    (bf16 autocast needs no GradScaler; the reference's scaler is an fp16 device.)  Returns ms per step."""
+    (bf16 autocast needs no GradScaler; the reference's scaler is an fp16 device.)  `optim`: the module the two
+    optimisers come from - torch.optim (the reference's call; default) or hbr_amd.optim (same interface on the fused
+    kernel, the optional sixth import line of INTEGRATION.md route A).  Returns (ms per step, last loss)."""
     import torch
+    optim = optim or torch.optim
     from hbr_amd.trainer import build_default_model
     from hbr_amd.vol_renderer import Volume_Renderer
     enc, denc, mlp = build_default_model(mn, sig, dev, seed=0)                                  # train_hash2.py:120-127
@@ -291,8 +294,10 @@ def main():
         dropin = None
         if rank == 0 and world == 1 and not args.no_dropin:
             ms, dl = dropin_leg(dev, batches, mn, sig, S, args.steps, args.warmup, total_steps, args.precision)
-            dropin = dict(ms_per_step=ms, value=R * S / (ms * 1e-3), loss=dl)
-            print(f"[bench] drop-in loop: {ms:.3f} ms/step", file=sys.stderr, flush=True)
+            import hbr_amd.optim as fused_optim
+            ms2, _ = dropin_leg(dev, batches, mn, sig, S, args.steps, args.warmup, total_steps, args.precision, optim=fused_optim)
+            dropin = dict(ms_per_step=ms, value=R * S / (ms * 1e-3), loss=dl, ms_fused_optim=ms2)
+            print(f"[bench] drop-in loop: {ms:.3f} ms/step (torch.optim), {ms2:.3f} ms/step (hbr_amd.optim)", file=sys.stderr, flush=True)
 
         # ---- CPU baseline: the oracle (a port of the reference's PyTorch-CPU path) on a bounded sample ---------
         cpu = None
@@ -321,6 +326,8 @@ def main():
                 "dist_backend": (torch.distributed.get_backend() if world > 1 else None),
                 # train_hash2.py:211-234 as written (vol_render + autograd + torch.optim), drop-in classes, same batches
                 "dropin_ms_per_step": dropin and dropin["ms_per_step"], "dropin_value": dropin and dropin["value"],
+                # the same loop with `from hbr_amd.optim import Adam, AdamW` in place of torch.optim's (same interface, fused kernel)
+                "dropin_fused_optim_ms_per_step": dropin and dropin["ms_fused_optim"],
             }
             print(json.dumps(line), flush=True)
         return line
