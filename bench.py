@@ -105,8 +105,8 @@ def dropin_leg(dev, batches, mn, sig, S, steps, warmup, total_steps, precision, 
     nerf = torch.nn.DataParallel(mlp, device_ids=[dev.index])
     vr = Volume_Renderer(H=800, W=800, K=torch.eye(3), near=2.0, far=6.0, device=dev, Pos_encode=enc, Dir_encode=denc,
                          max_dim=2 ** 10, sigma_val=sig.to(dev), mu=mn.to(dev))                  # :124-126
-    oe = torch.optim.Adam(enc.Embedding_list.parameters(), lr=0.05)                             # :141
-    om = torch.optim.AdamW(nerf.parameters(), lr=0.005)                                         # :142
+    oe = optim.Adam(enc.Embedding_list.parameters(), lr=0.05)                                   # :141
+    om = optim.AdamW(nerf.parameters(), lr=0.005)                                               # :142
     se = torch.optim.lr_scheduler.CosineAnnealingLR(oe, T_max=total_steps, eta_min=1e-4)        # :156-159
     sm = torch.optim.lr_scheduler.CosineAnnealingLR(om, T_max=total_steps, eta_min=1e-4)        # :160-162
     crit = torch.nn.MSELoss()                                                                   # :177
