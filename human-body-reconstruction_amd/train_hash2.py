@@ -112,8 +112,9 @@ def main(argv=None):
     vr = Volume_Renderer(H=H, W=W, K=None, near=near, far=far, device=dev, Pos_encode=enc, Dir_encode=denc, max_dim=2 ** 10,
                          sigma_val=sigma, mu=min_bound)
     if args.hierarchical:
-        oe = torch.optim.Adam(list(enc.Embedding_list.parameters()), lr=0.05)
-        om = torch.optim.AdamW(nerf.parameters(), lr=0.005)
+        from .optim import Adam, AdamW  # torch.optim's interface on the fused kernel (one launch per parameter group)
+        oe = Adam(list(enc.Embedding_list.parameters()), lr=0.05)
+        om = AdamW(nerf.parameters(), lr=0.005)
         se = torch.optim.lr_scheduler.CosineAnnealingLR(oe, T_max=total_steps, eta_min=1e-4)
         sm = torch.optim.lr_scheduler.CosineAnnealingLR(om, T_max=total_steps, eta_min=1e-4)
         crit = torch.nn.MSELoss()
