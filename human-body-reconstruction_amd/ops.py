@@ -31,7 +31,9 @@ def free_workspaces(device=None) -> int:
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """The current HIP stream of the current device as a raw handle.  (torch.cuda.current_stream().cuda_stream builds a
+    Stream object per call: ~9 us, eleven times per drop-in step; the raw getter is what torch's own compiled code uses.)"""
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def _elem_dtype(t: torch.Tensor, what: str) -> int:
@@ -97,10 +99,13 @@ class HashGeom:
         return len(self.scales)
 
     def c_args(self):
-        import ctypes as C
-        sc = (C.c_float * self.L)(*self.scales)
-        mu = (C.c_float * 3)(*self.mu)
-        return sc, mu
+        """(scales[L], mu[3]) as C float arrays; built once per geometry (the dataclass is frozen: cached on the instance)."""
+        c = self.__dict__.get("_c")
+        if c is None:
+            import ctypes as C
+            c = ((C.c_float * self.L)(*self.scales), (C.c_float * 3)(*self.mu))
+            object.__setattr__(self, "_c", c)
+        return c
 
 
 def precision_from_autocast() -> int:

@@ -78,29 +78,35 @@ class _FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         segs = []
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
                 continue
-            for p in ps:
-                if not p.is_cuda or p.dtype != torch.float32 or p.grad.is_sparse:
-                    raise ops.HbrError("hbr_amd.optim needs dense float32 parameters on the MI355X")
             self._state_for(group)
-            for p in ps:
-                self.state[p]["step"] += 1
-            k = int(self.state[ps[0]]["step"])
+            # step counters: one tensor shared by the group's parameters while they move together (one add per step
+            # instead of one per tensor; state_dict() shows it under every parameter, as torch's does with its own)
+            st0 = self.state[ps[0]]["step"]
+            if all(self.state[p]["step"] is st0 for p in ps[1:]):
+                st0 += 1
+            else:
+                if len(ps) == len(group["params"]) and all(float(self.state[p]["step"]) == float(st0) for p in ps[1:]):
+                    for p in ps[1:]:
+                        self.state[p]["step"] = st0   # equal counters (fresh state, or a loaded state_dict): share from now on
+                    st0 += 1
+                else:
+                    for p in ps:
+                        self.state[p]["step"] += 1
+            k = int(st0)
             b1, b2 = group["betas"]
             common = dict(lr=float(group["lr"]), beta1=b1, beta2=b2, eps=group["eps"], weight_decay=group["weight_decay"], step=k)
-            same_step = all(int(self.state[p]["step"]) == k for p in ps)
-            whole = len(ps) == len(group["params"]) and same_step
-            flat_p = _consecutive(ps) if whole else None
-            flat_g = _consecutive([p.grad for p in ps]) if flat_p is not None else None
-            flat_m = _consecutive([self.state[p]["exp_avg"] for p in ps]) if flat_g is not None else None
-            flat_v = _consecutive([self.state[p]["exp_avg_sq"] for p in ps]) if flat_m is not None else None
-            if flat_v is not None:
-                segs.append(dict(p=flat_p, g=flat_g, m=flat_m, v=flat_v, **common))
+            fast = self._fast_views(gi, group, ps) if all(int(self.state[p]["step"]) == k for p in (ps[0], ps[-1])) else None
+            flat_g = self._flat_grads(ps, fast) if fast is not None else None
+            if flat_g is not None:
+                segs.append(dict(p=fast[0], g=flat_g, m=fast[1], v=fast[2], **common))
             else:
                 for p in ps:
+                    if not p.is_cuda or p.dtype != torch.float32 or p.grad.is_sparse:
+                        raise ops.HbrError("hbr_amd.optim needs dense float32 parameters on the MI355X")
                     g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                     if not p.is_contiguous():
                         raise ops.HbrError("hbr_amd.optim needs contiguous parameters")
@@ -114,6 +120,44 @@ class _FusedAdam(torch.optim.Optimizer):
         for i in range(0, len(segs), 4):
             ops.adam_step_multi(segs[i:i + 4])
         return loss
+
+    def _fast_views(self, gi, group, ps):
+        """(flat parameters, flat exp_avg, flat exp_avg_sq, element offsets) of a group whose tensors and moments are
+        consecutive views of one buffer each - looked up once and kept while the first and last tensors stay where they
+        were (a .to() / load_state_dict that moves storage drops the entry)."""
+        if len(ps) != len(group["params"]):
+            return None
+        cache = self.__dict__.setdefault("_fast", {})
+        key = (ps[0].data_ptr(), ps[-1].data_ptr(), self.state[ps[0]]["exp_avg"].data_ptr(), self.state[ps[-1]]["exp_avg_sq"].data_ptr())
+        hit = cache.get(gi)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        flat_p = _consecutive(ps)
+        flat_m = _consecutive([self.state[p]["exp_avg"] for p in ps]) if flat_p is not None else None
+        flat_v = _consecutive([self.state[p]["exp_avg_sq"] for p in ps]) if flat_m is not None else None
+        views = None
+        if flat_v is not None:
+            offs, off = [], 0
+            for p in ps:
+                offs.append(off)
+                off += p.numel() * 4
+            views = (flat_p, flat_m, flat_v, offs)
+        cache[gi] = (key, views)
+        return views
+
+    @staticmethod
+    def _flat_grads(ps, fast):
+        """One flat view over the gradients if they are laid out exactly like the parameters (what ops.RenderFn hands
+        back and AccumulateGrad adopts), else None."""
+        g0 = ps[0].grad
+        base = g0.data_ptr()
+        if base % 16 or g0.dtype != torch.float32:
+            return None
+        for p, off in zip(ps, fast[3]):
+            g = p.grad
+            if g.data_ptr() != base + off or not g.is_contiguous():
+                return None
+        return torch.as_strided(g0, (fast[0].numel(),), (1,))
 
     @staticmethod
     def _unaligned(seg):
