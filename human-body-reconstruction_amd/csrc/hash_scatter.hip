@@ -146,10 +146,52 @@ __global__ __launch_bounds__(1024) void normalise_kernel(PointSrc ps, uint32_t N
   normalise(g, px, py, pz, nx, ny, nz);
   float* q = out + (size_t)(base + threadIdx.x) * 3;
   q[0] = nx; q[1] = ny; q[2] = nz;
-  // fminf / fmaxf skip a NaN: `finite` records that the box does not cover such a point
-  float v[7] = {nx, ny, nz, nx, ny, nz, (isfinite(nx) && isfinite(ny) && isfinite(nz)) ? 1.f : 0.f};
   auto lo = [](float a, float b) { return fminf(a, b); };
   auto hi = [](float a, float b) { return fmaxf(a, b); };
+  if (ps.x == nullptr) {
+    // Ray-generated points: a coordinate fl(o + fl(d t)) is monotonic in t, so a ray's extreme coordinates are those of
+    // its samples at min t and max t - whatever the order of t[] - and the stripe's box is the box of 2 x (rays in the
+    // stripe) end points.  ONE wave computes them (and the finiteness of t); the other fifteen skip the seven 64-lane
+    // reductions that were half of this kernel's instructions (17.5 -> ~12 us at the README batch).  The end points are
+    // whole-ray extremes: a ray only partly in this stripe widens this stripe's box, not the launch's (every ray is in it whole).
+    if (threadIdx.x >= 64) return;
+    const uint32_t lane = threadIdx.x;
+    float tlo = __uint_as_float(0x7f800000u), thi = -tlo, fin = 1.f;
+    for (uint32_t s2 = lane; s2 < ps.S; s2 += 64) {
+      const float tt = ps.t[s2];
+      tlo = fminf(tlo, tt); thi = fmaxf(thi, tt);
+      fin = isfinite(tt) ? fin : 0.f;
+    }
+    tlo = wave_reduce(tlo, lo); thi = wave_reduce(thi, hi); fin = wave_reduce(fin, lo);
+    const uint32_t last = min(base + 1023u, N - 1);
+    const uint32_t r0 = (__umulhi(base, ps.magic) + base) >> ps.shift, r1 = (__umulhi(last, ps.magic) + last) >> ps.shift;
+    const float inf = __uint_as_float(0x7f800000u);
+    float v[7] = {inf, inf, inf, -inf, -inf, -inf, fin};
+    for (uint32_t k = lane; k < 2u * (r1 - r0 + 1u); k += 64) {
+      const uint32_t r = r0 + (k >> 1);
+      const float tt = (k & 1u) ? thi : tlo;
+      const float* o = ps.o + (size_t)r * 3;
+      const float* d = ps.d + (size_t)r * 3;
+      float ex, ey, ez;  // load_point's arithmetic (vol_renderer.py:165), then normalise's
+      normalise(g, __fadd_rn(o[0], __fmul_rn(d[0], tt)), __fadd_rn(o[1], __fmul_rn(d[1], tt)), __fadd_rn(o[2], __fmul_rn(d[2], tt)), ex, ey, ez);
+      v[0] = fminf(v[0], ex); v[1] = fminf(v[1], ey); v[2] = fminf(v[2], ez);
+      v[3] = fmaxf(v[3], ex); v[4] = fmaxf(v[4], ey); v[5] = fmaxf(v[5], ez);
+      v[6] = (isfinite(ex) && isfinite(ey) && isfinite(ez)) ? v[6] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[k] = wave_reduce(v[k], lo);
+#pragma unroll
+    for (int k = 3; k < 6; ++k) v[k] = wave_reduce(v[k], hi);
+    v[6] = wave_reduce(v[6], lo);
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) part[(size_t)blockIdx.x * 7 + k] = v[k];
+    }
+    return;
+  }
+  // explicit points: every wave reduces its 64, then one more row reduction over the 16 waves
+  // fminf / fmaxf skip a NaN: `finite` records that the box does not cover such a point
+  float v[7] = {nx, ny, nz, nx, ny, nz, (isfinite(nx) && isfinite(ny) && isfinite(nz)) ? 1.f : 0.f};
 #pragma unroll
   for (int k = 0; k < 3; ++k) v[k] = wave_reduce(v[k], lo);  // DPP: 42 __shfl_xor (ds_bpermute) made the kernel LDS-bound
 #pragma unroll
