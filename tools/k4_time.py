@@ -5,6 +5,7 @@ import torch, ref_cpu
 from hbr_amd import ops
 from hbr_amd._lib import PLANAR, BF16
 dev = "cuda:0"
+torch.manual_seed(0)
 R, S = 16000, 128
 N = R * S
 o, d, dn, gt = ref_cpu.synthetic_rays(R, seed=0)
@@ -22,4 +23,12 @@ e0.record()
 for _ in range(20):
     ops.mlp_bwd(feat, PLANAR, pe, S, P, BF16, dout, dP, absmax_out=amax)
 e1.record(); torch.cuda.synchronize()
+dP.zero_()
+df = ops.mlp_bwd(feat, PLANAR, pe, S, P, BF16, dout, dP, absmax_out=amax)
+torch.cuda.synchronize()
+import hashlib
+# bit-for-bit fingerprints: d feat and absmax do not depend on summation order; dP does only through the order in which
+# a wave adds its tiles (same grid => same order)
+print("fingerprint dfeat", hashlib.sha1(df.view(torch.int16 if df.dtype == torch.bfloat16 else torch.int32).cpu().numpy().tobytes()).hexdigest()[:16],
+      "absmax", hashlib.sha1(amax.cpu().numpy().tobytes()).hexdigest()[:16], "dP sum", float(dP.double().abs().sum()), flush=True)
 print(os.environ.get("HBR_LIB", "default"), f"mlp_bwd bf16 {e0.elapsed_time(e1) / 20:.4f} ms", flush=True)
