@@ -182,6 +182,14 @@ def main():
             torch.distributed.init_process_group("nccl", device_id=dev)
         else:
             torch.distributed.init_process_group(backend)
+    # One-GPU RCCL rehearsal (HBR_RCCL_REHEARSAL=1, world == 1 only): a one-rank RCCL group, the half-level scatter
+    # launches and the three staged all-reduces issued as in the multi-GPU step - what the step pays for the stream
+    # hand-offs and the split before any byte crosses xGMI.  The line says so in `config.rccl_rehearsal`.
+    rehearsal = world == 1 and os.environ.get("HBR_RCCL_REHEARSAL") == "1"
+    if rehearsal:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     assert _lib.lib().hbr_device_ok() == 1, "not a gfx950 device"
 
     def run(scaling):
@@ -205,7 +213,11 @@ def main():
         fdt = prec if args.feat_dtype == "auto" else (_lib.BF16 if args.feat_dtype == "bf16" else _lib.F32)
         total_steps = 4000 * 1000  # train_hash2.py:156-157: epochs * len(loader) (1000 epochs x 4000 batches of the 64M lego rays)
         tr = HashNeRFTrainer(enc, mlp, near=2.0, far=6.0, num_samples=S, total_steps=total_steps, precision=prec, feat_dtype=fdt,
-                             overlap_comm=os.environ.get("HBR_OVERLAP_COMM", "1") != "0")  # A/B switch for the staged all-reduce
+                             overlap_comm=os.environ.get("HBR_OVERLAP_COMM", "1") != "0",  # A/B switch for the staged all-reduce
+                             split_scatter=True if rehearsal and os.environ.get("HBR_OVERLAP_COMM", "1") != "0" else None)
+        tr.always_reduce = rehearsal
+        if os.environ.get("HBR_SPLIT_LEVEL"):
+            tr.split_level = int(os.environ["HBR_SPLIT_LEVEL"])
         torch.manual_seed(1234)  # identical jitter t[S] on every rank
 
         def sync():
@@ -217,6 +229,11 @@ def main():
             ms, dl = dropin_leg(dev, batches, mn, sig, S, args.steps, args.warmup, total_steps, args.precision)
             print(json.dumps({"dropin_ms_per_step": ms, "dropin_value": R * S / (ms * 1e-3), "loss": dl, "steps": args.steps}), flush=True)
             return
+        # world > 1 and no explicit HBR_OVERLAP_COMM: the trainer measures the one-collective and the staged step on
+        # this node and keeps the faster (same bits either way); its steps are ordinary training steps, before warm-up
+        tune = None
+        if (world > 1 or rehearsal) and "HBR_OVERLAP_COMM" not in os.environ:
+            tune = tr.autotune_comm(lambda i: batches[i % pool])
         print(f"[bench] rank {rank}/{world}: model + {pool} batches resident, warming up", file=sys.stderr, flush=True)
         for i in range(args.warmup):
             tr.step(*batches[i % pool])
@@ -322,8 +339,9 @@ def main():
                 "cpu_baseline": cpu,
                 # multi-GPU diagnostics: the one all-reduce per step of the flat 8.05 MiB gradient buffer
                 "allreduce_exposed_ms": comm_ms, "overlap_comm": bool(tr.overlap_comm), "split_scatter": bool(tr.split_scatter),
-                "allreduce_bytes": int(tr.grad.numel() * 4) if world > 1 else 0,
-                "dist_backend": (torch.distributed.get_backend() if world > 1 else None),
+                "allreduce_bytes": int(tr.grad.numel() * 4) if (world > 1 or rehearsal) else 0,
+                "dist_backend": (torch.distributed.get_backend() if (world > 1 or rehearsal) else None),
+                "rccl_rehearsal": rehearsal, "comm_autotune": tune,
                 # train_hash2.py:211-234 as written (vol_render + autograd + torch.optim), drop-in classes, same batches
                 "dropin_ms_per_step": dropin and dropin["ms_per_step"], "dropin_value": dropin and dropin["value"],
                 # the same loop with `from hbr_amd.optim import Adam, AdamW` in place of torch.optim's (same interface, fused kernel)

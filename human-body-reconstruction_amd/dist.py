@@ -70,13 +70,15 @@ class StagedAllReduce:
     all but the last piece overlap the kernels still producing the rest (RCCL runs them on its own stream; `launch`
     orders a piece after everything already enqueued on the caller's current stream, `finish` makes the current stream
     wait for all of them).  The pieces partition the buffer, so the result is bit-identical to one collective over
-    the whole buffer.  With world == 1 every call is a no-op."""
+    the whole buffer.  With world == 1 every call is a no-op, unless `force` (the one-GPU RCCL rehearsal of
+    tests/test_gpu_rccl_world1.py: a one-rank all-reduce leaves the data as it is but takes the same stream hand-offs)."""
 
-    def __init__(self, world: int, group=None):
+    def __init__(self, world: int, group=None, force: bool = False):
         self.world, self.group, self._works = world, group, []
+        self.active = world > 1 or (force and dist.is_initialized())
 
     def launch(self, piece: torch.Tensor) -> None:
-        if self.world > 1 and piece.numel():
+        if self.active and piece.numel():
             self._works.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self) -> None:

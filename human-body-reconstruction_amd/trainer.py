@@ -38,7 +38,7 @@ class HashNeRFTrainer:
     def __init__(self, encoder: HashEncoder, mlp: MLP_3D, near: float = 2.0, far: float = 6.0, num_samples: int = 128,
                  total_steps: int = 100000, lr_embed: float = 0.05, lr_mlp: float = 0.005, eta_min: float = 1e-4,
                  weight_decay_mlp: float = 0.01, precision: int = BF16, feat_dtype: Optional[int] = None, num_freq: int = 4,
-                 process_group=None, scatter_algo: int = 0, overlap_comm: bool = True, split_scatter: Optional[bool] = None,
+                 process_group=None, scatter_algo: int = 0, overlap_comm: bool = False, split_scatter: Optional[bool] = None,
                  seed: int = 0):
         self.enc, self.mlp = encoder, mlp
         self.near, self.far, self.S = float(near), float(far), int(num_samples)
@@ -58,10 +58,15 @@ class HashNeRFTrainer:
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
-        # The scatter kernel runs as two half-level launches so that each half's all-reduce overlaps the other half's
-        # kernel.  Default: only when there is something to overlap (world > 1); tests force it on a single GPU, where
-        # the staged reduce is a no-op and the result must equal the single launch.
+        # overlap_comm: the scatter kernel runs as two launches so that the first one's all-reduce overlaps the second
+        # launch.  Off by default since round 3: on one MI355X with a one-rank RCCL group the staging itself costs
+        # ~0.1 ms per step, more than an 8 MiB all-reduce over xGMI is expected to take - `autotune_comm`
+        # measures both on the node it runs on (bench.py does that).  Tests force the split on a single GPU, where the
+        # staged reduce is a no-op and the result must equal the single launch.
         self.split_scatter = (self.world > 1 and overlap_comm) if split_scatter is None else bool(split_scatter)
+        self.always_reduce = False  # tests: issue the collectives with world == 1 too (RCCL stream hand-offs on one GPU)
+        # first level of the FIRST scatter launch (levels [split_level, L), reduced while [0, split_level) are scattered)
+        self.split_level = max(1, encoder.geometry().L // 2)
         self._bind_parameters()
         dev = self.tables.device
         self.geom = encoder.geometry()
@@ -101,6 +106,35 @@ class HashNeRFTrainer:
         e1.record()
         self.timers.setdefault(name, []).append((e0, e1))
         return r
+
+    def autotune_comm(self, batch_fn, steps: int = 20) -> dict:
+        """world > 1: runs `steps` training steps with the step's all-reduce as ONE collective behind the scatter kernel
+        and `steps` with it staged (two half-level scatter launches, the first piece reduced under the second launch),
+        takes the slower rank's time for each (one MAX all-reduce, so every rank decides alike) and keeps the faster.
+        Both ways produce the same bits (tests/test_gpu_shipped_paths.py, tests/test_gpu_rccl_world1.py), so this is a
+        pure scheduling choice: the staging costs ~0.1 ms per step of its own and pays only where the
+        collective is slower than that.  `batch_fn(i)` -> (rays_o, rays_d, dir_norm, gt).  Returns the measurements."""
+        import time
+        if not (self.world > 1 or (self.always_reduce and torch.distributed.is_initialized())) or self.geom.L < 2:
+            return {}
+        res, dev = {}, self.tables.device
+        for name, split in (("single", False), ("staged", True)):
+            self.split_scatter = split
+            for i in range(2):  # workspaces, RCCL channels for this message size
+                self.step(*batch_fn(i))
+            torch.cuda.synchronize(dev)
+            torch.distributed.barrier(group=self.pg)
+            t0 = time.perf_counter()
+            for i in range(steps):
+                self.step(*batch_fn(i))
+            torch.cuda.synchronize(dev)
+            dt = torch.tensor([(time.perf_counter() - t0) / steps * 1e3], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX, group=self.pg)
+            res[name + "_ms_per_step"] = float(dt.item())
+        self.split_scatter = res["staged_ms_per_step"] < res["single_ms_per_step"]
+        self.overlap_comm = self.split_scatter
+        res["chosen"] = "staged" if self.split_scatter else "single"
+        return res
 
     def sample_t(self, device) -> torch.Tensor:
         """This step's shared depths t[S]: one launch, jitter drawn on the device from (seed, step) - every rank that
@@ -144,23 +178,25 @@ class HashNeRFTrainer:
         dfeat = self._timed("mlp_bwd", lambda: ops.mlp_bwd(feat, PLANAR, pe, S, self.flat, self.precision, d_out, self.g_mlp,
                                                            absmax_out=amax, image_ready=True, overwrite=True))
         if self.split_scatter and g.L >= 2:
-            # The step's one all-reduce, issued in three pieces that partition the flat gradient buffer: the MLP block
-            # (final after K4), then the upper half of the levels while the lower half's scatter is still running.
-            # Only the last piece (4 MiB at L = 16) is exposed.  Planar [L,N,2] dfeat and [L,T,F] grads make a level
+            # The step's one all-reduce, issued in two pieces that partition the flat gradient buffer: the upper levels
+            # together with the MLP block (final after K4) while the lower levels' scatter is still running, then the
+            # lower levels - the only exposed piece (4 MiB at L = 16, split_level = 8).  What the staging itself costs
+            # (two launches instead of one, the stream hand-offs): DESIGN 6; `autotune_comm` measures both ways.  Planar [L,N,2] dfeat and [L,T,F] grads make a level
             # range a contiguous slice, so the same kernel runs on each half (bit-identical to the single launch:
             # tests/test_gpu_shipped_paths.py).  With world == 1 the reduce calls are no-ops.
-            red = StagedAllReduce(self.world, self.pg)
-            nt, half = self.n_tab, g.L // 2
+            red = StagedAllReduce(self.world, self.pg, force=self.always_reduce)
+            nt, half = self.n_tab, min(max(1, int(self.split_level)), g.L // 2)
             cut = half * g.T * g.F
-            red.launch(self.grad[nt:])
 
             def scatter_halves():  # timed as ONE hash_bwd span (both launches), like the single-launch path
-                # the second half re-uses the first half's coordinates (algo 2 then 3) - where the LDS kernels can run at
-                # all: for a shape they refuse (T > 2^28: workspace size 0) both halves take the caller's algo, so a
-                # model that trains on one GPU does not raise on N
+                # the second launch re-uses the first one's coordinates (algo 2 then 3; the first is the larger, so its
+                # workspace fits both) - where the LDS kernels can run at all: for a shape they refuse (T > 2^28:
+                # workspace size 0) both take the caller's algo, so a model that trains on one GPU does not raise on N
                 lds = (self.scatter_algo in (0, 2) and R * S >= 65536
-                       and _lib.lib().hbr_hash_bwd_workspace_bytes(R * S, half, g.T, g.F, 2) > 0)
-                for k, (lo, hi, piece) in enumerate(((half, g.L, self.grad[cut:nt]), (0, half, self.grad[:cut]))):
+                       and _lib.lib().hbr_hash_bwd_workspace_bytes(R * S, g.L - half, g.T, g.F, 2) > 0)
+                # pieces: [upper levels | MLP block] - contiguous in the flat buffer, final once K4 and the first launch
+                # are done - then the lower levels
+                for k, (lo, hi, piece) in enumerate(((half, g.L, self.grad[cut:]), (0, half, self.grad[:cut]))):
                     sub = ops.HashGeom(g.scales[lo:hi], g.mu, g.sigma, g.T, g.F)
                     ops.hash_encode_bwd(sub, dfeat[lo:hi], self.g_tab[lo:hi], rays=rays, layout=PLANAR,
                                         algo=(2 if k == 0 else 3) if lds else self.scatter_algo,
@@ -168,12 +204,12 @@ class HashNeRFTrainer:
                     red.launch(piece)
 
             self._timed("hash_bwd", scatter_halves)
-            self._timed("allreduce_exposed", red.finish) if self.world > 1 else red.finish()
+            self._timed("allreduce_exposed", red.finish) if red.active else red.finish()
         else:
             self._timed("hash_bwd", lambda: ops.hash_encode_bwd(g, dfeat, self.g_tab, rays=rays, layout=PLANAR, algo=self.scatter_algo,
                                                                 dy_absmax=amax, overwrite=True))
             # the one collective of the step
-            if self.world > 1:
+            if self.world > 1 or (self.always_reduce and torch.distributed.is_initialized()):
                 self._timed("allreduce_exposed", lambda: torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM, group=self.pg))
         # optimiser (dense Adam over every table row, as the reference's torch.optim.Adam does)
         k = self.step_count

@@ -34,7 +34,7 @@ def _worker(rank, world, port, out_dir):
     torch.cuda.set_device(dev)
     hd.init_from_env(backend="gloo")
     batch, enc, mlp = _setup(dev)
-    tr = HashNeRFTrainer(enc, mlp, num_samples=S, total_steps=100, seed=9)
+    tr = HashNeRFTrainer(enc, mlp, num_samples=S, total_steps=100, seed=9, overlap_comm=True)
     assert tr.world == world and tr.split_scatter
     shard = hd.shard_batch(batch, rank, world)
     losses = [float(tr.step(*shard)) for _ in range(2)]
