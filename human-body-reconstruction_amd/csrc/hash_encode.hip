@@ -39,6 +39,12 @@ __global__ __launch_bounds__(kFwdThreads) void hash_fwd_kernel(PointSrc ps, uint
     corner_weights(c, w);
     const float2* tab = (const float2*)tables + (size_t)l * g.T;
     float2 fv[8];
+#ifdef HBR_K1_ABLATE_BELOW  // timing-only variant: levels below this take no table reads (upper bound of an LDS-staged tile)
+    if (l < HBR_K1_ABLATE_BELOW) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) fv[k] = make_float2(__uint_as_float(rows[k]), w[k]);
+    } else
+#endif
 #pragma unroll
     for (int k = 0; k < 8; ++k) fv[k] = tab[rows[k]];
     // (fv*w).sum(-2): products rounded, then added (hash_encoding.py:144)
