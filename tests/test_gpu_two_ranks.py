@@ -39,7 +39,12 @@ def _worker(rank, world, port, out_dir):
     shard = hd.shard_batch(batch, rank, world)
     losses = [float(tr.step(*shard)) for _ in range(2)]
     torch.cuda.synchronize()
-    torch.save({"grad": tr.grad.cpu(), "tables": tr.tables.cpu(), "flat": tr.flat.cpu(), "losses": losses}, os.path.join(out_dir, f"r{rank}.pt"))
+    out = {"grad": tr.grad.cpu(), "tables": tr.tables.cpu(), "flat": tr.flat.cpu(), "losses": losses}
+    # autotune_comm: both ranks must reach the same decision (it is taken from one MAX all-reduce) and stay replicas
+    tune = tr.autotune_comm(lambda i: shard, steps=2)
+    torch.cuda.synchronize()
+    out.update(chosen=tune["chosen"], tuned_ms=[tune["single_ms_per_step"], tune["staged_ms_per_step"]], tables_after_tune=tr.tables.cpu())
+    torch.save(out, os.path.join(out_dir, f"r{rank}.pt"))
     torch.distributed.destroy_process_group()
 
 
@@ -53,6 +58,7 @@ def test_two_rank_trainer_step_equals_single_process(tmp_path):
     r1 = torch.load(tmp_path / "r1.pt", weights_only=True)
     # replicas stay identical: same reduced gradient, same parameters after two optimiser steps
     assert torch.equal(r0["grad"], r1["grad"]) and torch.equal(r0["tables"], r1["tables"]) and torch.equal(r0["flat"], r1["flat"])
+    assert r0["chosen"] == r1["chosen"] and r0["tuned_ms"] == r1["tuned_ms"] and torch.equal(r0["tables_after_tune"], r1["tables_after_tune"])
     dev = torch.device("cuda", 0)
     batch, enc, mlp = _setup(dev)
     tr = HashNeRFTrainer(enc, mlp, num_samples=S, total_steps=100, seed=9)
