@@ -526,6 +526,45 @@ __device__ __forceinline__ void load_tile_in(const FeatSrc& fs, const PeSrc& ps,
   }
 }
 
+// The fast path's loads of one tile in SIX parts (two vector-memory instructions each), for the backward kernel: its four
+// waves run in lockstep, so twelve loads issued back to back by each of them queue at the CU's one address unit (16
+// cycles per 64-lane instruction: ~660 cycles of issue stall per tile, profiles/r02_h_k4_phases.txt); two at a time
+// between the exchange steps they are taken in the shadow of the MFMA / LDS work.  PART 0..3: level pairs; 4: peA, peB;
+// 5: peC, d out.  Same addresses and values as load_tile_in's fast path.
+template <int DT, int PART>
+__device__ __forceinline__ void load_tile_part(const FeatSrc& fs, const PeSrc& ps, const float* dout, const TileCursor& c, bool valid,
+                                               int h, TileIn& ti) {
+  constexpr int ES = DT == HBR_F32 ? 8 : 4;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (PART < 4) {
+    ti.v[2 * PART] = make_float2(0.f, 0.f);
+    ti.v[2 * PART + 1] = make_float2(0.f, 0.f);
+    if (valid) {
+      const uint32_t off = planar_off<ES>(fs.N, c.n, h);
+#pragma unroll
+      for (int k = 2 * PART; k < 2 * PART + 2; ++k) {
+        const char* lb = (const char*)fs.p + planar_level_base<ES>(fs.N, k);
+        if (DT == HBR_F32) ti.v[k] = *(const float2*)(lb + off);
+        else ti.v[k].x = __uint_as_float(*(const uint32_t*)(lb + off));
+      }
+    }
+  } else if constexpr (PART == 4) {
+    ti.peA = z4; ti.peB = z4;
+    if (valid) {
+      const char* pr = (const char*)ps.pe + (c.ray * 96u + 16u * (uint32_t)h);
+      ti.peA = *(const float4*)pr;
+      ti.peB = *(const float4*)(pr + 32);
+    }
+  } else {
+    ti.peC = z4; ti.dO = z4;
+    if (valid) {
+      const char* pr = (const char*)ps.pe + (c.ray * 96u + 16u * (uint32_t)h);
+      ti.peC = *(const float4*)(pr + 64);
+      if (h == 0) ti.dO = *(const float4*)((const char*)dout + c.n * 16u);
+    }
+  }
+}
+
 // one point's 32 features -> the S32 fragments of the single input tile
 template <class P, int DT>
 __device__ __forceinline__ void feat_frags(const TileIn& ti, typename P::frag (&x)[P::S32]) {
@@ -1239,13 +1278,23 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
   load_tile_in<LAYOUT, DT, true>(fs, ps, dout, ahead, ahead.n < fs.N, h, nxt);
   PhaseClock pc;
   pc.start();
+#ifndef HBR_K4_SPREAD
+#define HBR_K4_SPREAD 1  // 0: all twelve loads of the next tile at the top of the round (A/B builds)
+#endif
   for (uint32_t r = 0; r < rounds; ++r) {
     const uint32_t tile = blockIdx.x * 4 + wv + r * stride;
     const uint32_t n = tile * 32 + (lane & 31);
     const bool valid = tile < ntiles && n < fs.N;
     const TileIn cur = nxt;
     ahead.advance();  // n < N implies its tile exists; N < 2^31 and at most one round past the end: no wrap-around
-    load_tile_in<LAYOUT, DT, true>(fs, ps, dout, ahead, ahead.n < fs.N, h, nxt);
+    // Round 3: on the fast path the next tile's loads go out two at a time between the exchange steps (load_tile_part):
+    // 0.3957 -> 0.3876 ms stand-alone, same bits.  (Deferring the eight d feat stores the same way was measured too:
+    // 0.3937 ms - the carried words cost more than the stores' issue stalls; not kept.)
+    const bool spread = HBR_K4_SPREAD && LAYOUT == HBR_LAYOUT_PLANAR && fs.addr32;  // uniform
+    const bool nvalid = ahead.n < fs.N;
+    if (!spread) load_tile_in<LAYOUT, DT, true>(fs, ps, dout, ahead, nvalid, h, nxt);
+    else load_tile_part<DT, 0>(fs, ps, dout, ahead, nvalid, h, nxt);
+#define HBR_LOAD_PART(PART) if (spread) load_tile_part<DT, PART>(fs, ps, dout, ahead, nvalid, h, nxt)
     pc.mark(0);  // next tile's loads issued
     Saved<P> sv;
     if constexpr (P::ELEMS == 8) forward_tile_prefetched<DT>(img, cur, lane, sv, pc);
@@ -1272,11 +1321,13 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
     // ---- C2
     typename P::frag dzc2[2 * P::S32];
     dense_mask_take<P, 2, P::S8, 2, 1>(img, T::b_base(C3), lofs, wq, dz3, sv.c2, dzc2, xch, buf, lane, wv, acc[C3], ba, C3, pc, 2);
+    HBR_LOAD_PART(1);
     dense_request<P, 2, 2 * P::S32>(img, T::b_base(C2), lofs, wq);
     xch_put<P, 2, 2, 2 * P::S32, 2 * P::S32>(xch, buf, lane, wv, sv.c1, dzc2, bsum + db_base(C2));
     // ---- C1
     typename P::frag dzc1[2 * P::S32];
     dense_mask_take<P, 2, 2 * P::S32, 2, 2>(img, T::b_base(C2), lofs, wq, dzc2, sv.c1, dzc1, xch, buf, lane, wv, acc[C2], ba, C2, pc, 5);
+    HBR_LOAD_PART(2);
     xch_put<P, 2, 2, P::S32 + P::S8, 2 * P::S32>(xch, buf, lane, wv, sv.cin, dzc1, bsum + db_base(C1));  // take: after the next layer's dense
     // ---- L3: ds rows 1..15 = d cin slots 1..15 ; row 0 = d sigma * lrelu'(s0)
     typename P::frag dz_s[P::S16];
@@ -1288,16 +1339,19 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
       for (int s = 0; s < P::S16; ++s) dz_s[s] = P::from_acc(a[0], s);
     }
     xch_take<P, 2, 2>(xch, buf, lane, wv, acc[C1], ba, C1, pc, 8);
+    HBR_LOAD_PART(3);
     dense_request<P, 2, P::S16>(img, T::b_base(L3), lofs, wq);
     xch_put<P, 2, 1, 2 * P::S32, P::S16>(xch, buf, lane, wv, sv.h2, dz_s, bsum + db_base(L3));
     // ---- L2
     typename P::frag dz2[2 * P::S32];
     dense_mask_take<P, 2, P::S16, 2, 1>(img, T::b_base(L3), lofs, wq, dz_s, sv.h2, dz2, xch, buf, lane, wv, acc[L3], ba, L3, pc, 11);
+    HBR_LOAD_PART(4);
     dense_request<P, 2, 2 * P::S32>(img, T::b_base(L2), lofs, wq);
     xch_put<P, 2, 2, 2 * P::S32, 2 * P::S32>(xch, buf, lane, wv, sv.h1, dz2, bsum + db_base(L2));
     // ---- L1
     typename P::frag dz1[2 * P::S32];
     dense_mask_take<P, 2, 2 * P::S32, 2, 2>(img, T::b_base(L2), lofs, wq, dz2, sv.h1, dz1, xch, buf, lane, wv, acc[L2], ba, L2, pc, 14);
+    HBR_LOAD_PART(5);
     xch_put<P, 1, 2, P::S32, 2 * P::S32>(xch, buf, lane, wv, sv.x0, dz1, bsum + db_base(L1));  // take: after the next layer's dense
     // ---- d feat
     if (dfd.p) {
@@ -1349,6 +1403,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
       }
     }
     xch_take<P, 1, 2>(xch, buf, lane, wv, acc[L1], ba, L1, pc, 17);
+#undef HBR_LOAD_PART
   }
 
   pc.finish();
