@@ -52,6 +52,9 @@ def build_parser():
     p.add_argument("--synthetic", type=int, default=0, help="train on N synthetic rays instead of a dataset")
     p.add_argument("--steps", type=int, default=0, help="stop after this many optimiser steps (0 = all epochs)")
     p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--overlap_comm", default="off", choices=["off", "on", "auto"],
+                   help="more than one GPU: the step's all-reduce as one collective behind the scatter kernel (off), staged under a "
+                        "split scatter launch (on), or measured both ways on the first batches and the faster kept (auto)")
     p.add_argument("--out_dir", default="./results")
     return p
 
@@ -107,7 +110,8 @@ def main(argv=None):
     n_batches = max(1, rays_o.shape[0] // args.num_batch)
     total_steps = args.num_epochs * n_batches
     prec = _lib.BF16 if args.precision == "bf16" else _lib.F32
-    tr = HashNeRFTrainer(enc, mlp, near=near, far=far, num_samples=args.num_samples, total_steps=total_steps, precision=prec)
+    tr = HashNeRFTrainer(enc, mlp, near=near, far=far, num_samples=args.num_samples, total_steps=total_steps, precision=prec,
+                         overlap_comm=args.overlap_comm == "on")
     hdist.broadcast_params_([tr.tables, tr.flat])
     vr = Volume_Renderer(H=H, W=W, K=None, near=near, far=far, device=dev, Pos_encode=enc, Dir_encode=denc, max_dim=2 ** 10,
                          sigma_val=sigma, mu=min_bound)
@@ -119,6 +123,15 @@ def main(argv=None):
         sm = torch.optim.lr_scheduler.CosineAnnealingLR(om, T_max=total_steps, eta_min=1e-4)
         crit = torch.nn.MSELoss()
 
+    if world > 1 and args.overlap_comm == "auto" and not args.hierarchical:
+        def first_batches(i):  # this rank's shard of the first batches in loader order (ordinary training steps)
+            idx = torch.arange(i * args.num_batch, (i + 1) * args.num_batch, device=dev) % rays_o.shape[0]
+            lo, hi = hdist.shard_bounds(idx.shape[0], rank, world)
+            idx = idx[lo:hi]
+            return rays_o[idx], rays_d[idx], dir_norms[idx], gts[idx]
+        tune = tr.autotune_comm(first_batches)
+        if rank == 0:
+            print(f"all-reduce schedule: {tune}")
     iters = max(1, n_batches // 100)  # train_hash2.py:189: 100 images per epoch
     step, t0, loss = 0, time.time(), None
     gen = torch.Generator(device=dev).manual_seed(0)  # same shuffle on every rank
