@@ -349,6 +349,21 @@ struct SegDy {
       d1 = bf16_hi(w);
     }
   }
+  // feature f of the segment's m-th point alone.  bf16: ONE v_perm_b32 moves the chosen half of the packed pair into the
+  // upper half of a zero word (`sel` = pick_selector(f), wave-uniform) - the hashed visit is VALU-issue bound, and
+  // shift + mask + select of the two decoded values were 3 of its ~70 instructions.
+  __device__ __forceinline__ static uint32_t pick_selector(int f) { return f ? 0x07060c0cu : 0x05040c0cu; }
+  __device__ __forceinline__ float pick(int m, int f, uint32_t sel) const {
+    if (DTYPE == HBR_F32) {
+      float d0, d1;
+      get(m, d0, d1);
+      return f ? d1 : d0;
+    } else {
+      const uint4 q = v[m >> 2];
+      const uint32_t w = (m & 3) == 0 ? q.x : ((m & 3) == 1 ? q.y : ((m & 3) == 2 ? q.z : q.w));
+      return __uint_as_float(__builtin_amdgcn_perm(w, 0u, sel));
+    }
+  }
   // vector path usable for this level: planar, and the level's first byte 16-byte aligned
   __device__ __forceinline__ static bool aligned(const void* dy, int l, uint32_t N) {
     return ((((uintptr_t)dy) + (size_t)l * N * (DTYPE == HBR_F32 ? 8 : 4)) & 15) == 0;
@@ -483,6 +498,7 @@ __device__ __forceinline__ void hashed_slice_body(const uint32_t b, unsigned lon
   // slice-select bits -> the visit needs no per-point range check (NONNEG / BOXED above; 0.594 -> 0.587 ms).
   const bool nonneg = meta->finite && meta->lo[0] >= 0.f && meta->lo[1] >= 0.f && meta->lo[2] >= 0.f && scale >= 0.f &&
                       __fmul_rn(meta->hi[0], scale) < (float)(kSliceRows - 2);
+  const uint32_t psel = SegDy<DTYPE>::pick_selector(f);
   auto sweep = [&](auto nonneg_tag) {
     for (uint32_t s = s_begin + wv; s < s_end; s += kLdsBwdThreads / 64) {
       const float* q = xnorm + ((size_t)s * 1024u + lane) * 3;
@@ -495,9 +511,7 @@ __device__ __forceinline__ void hashed_slice_body(const uint32_t b, unsigned lon
         for (int m = 0; m < kSeg; ++m) {
           const float* qn = q + (m + 1 < kSeg ? (m + 1) : m) * 64 * 3;  // next step's coordinates, requested before this step's arithmetic
           const float ax = qn[0], ay = qn[1], az = qn[2];
-          float d0, d1;
-          seg.get(m, d0, d1);
-          visit(nonneg_tag, nx, ny, nz, f ? d1 : d0);
+          visit(nonneg_tag, nx, ny, nz, seg.pick(m, f, psel));
           nx = ax; ny = ay; nz = az;
         }
       } else {  // last (partial) stripe, rows layout, or an unaligned level: one clamped load per visit
