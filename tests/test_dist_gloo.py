@@ -67,11 +67,19 @@ def _worker(rank, world, port, out_dir):
         red.launch(piece)
     red.finish()
     staged.mul_(1.0 / world)
+    # ... and in the two pieces the trainer issues since round 3: [upper levels | MLP block], then the lower levels
+    staged2 = flat.clone()
+    red = hd.StagedAllReduce(world)
+    assert red.active
+    for piece in (staged2[cut:], staged2[:cut]):
+        red.launch(piece)
+    red.finish()
+    staged2.mul_(1.0 / world)
     # ... and the list form the --hierarchical route uses (28 tensors packed into one collective)
     pieces = [flat[:cut].clone(), flat[cut:nt].clone().view(-1, 2), flat[nt:].clone()]
     hd.allreduce_mean_grads_(pieces, world)
     hd.allreduce_mean_(flat, world)
-    assert torch.equal(staged, flat)
+    assert torch.equal(staged, flat) and torch.equal(staged2, flat)
     assert torch.equal(torch.cat([p.reshape(-1) for p in pieces]), flat)
     torch.save(flat, os.path.join(out_dir, f"g{rank}.pt"))
     torch.distributed.destroy_process_group()
@@ -87,6 +95,20 @@ def test_sharded_gradient_equals_single_process(tmp_path):
     full = _flat_grad(batch, t, tables, params, scales, mn, sig)
     # mean over equal shards of per-shard mean losses == mean over all rays (up to summation order)
     assert torch.allclose(g0, full, rtol=1e-4, atol=1e-6 * float(full.abs().max()))
+
+
+def test_staged_allreduce_is_inert_without_a_group():
+    """world == 1: no collective is issued - not even with force=True - unless a process group exists (the one-rank RCCL
+    rehearsal of tests/test_gpu_rccl_world1.py initialises one)."""
+    from hbr_amd import dist as hd
+    assert not torch.distributed.is_initialized()
+    x = torch.arange(8.0)
+    for force in (False, True):
+        red = hd.StagedAllReduce(1, force=force)
+        assert not red.active
+        red.launch(x)
+        red.finish()
+    assert torch.equal(x, torch.arange(8.0))
 
 
 def test_shard_bounds_cover_and_are_equal():
