@@ -11,7 +11,19 @@ constexpr int kXcds = 8;
 // j-th level of XCD group `group`: groups pair a coarse level (cheap: the wave's gathers coalesce) with a fine one
 // (texture-rate bound) - {k, 15-k} for L = 16 - so that the 8 XCDs finish together; each XCD's L2 still only sees
 // L/8 levels.
-__device__ __forceinline__ int group_level(int group, int j) { return 8 * j + ((j & 1) ? 7 - group : group); }
+// Round 3: measured one level at a time (profiles/r03_k1_level_costs.txt) the cost keeps rising to the finest level -
+// 7 / 40 / 182 us beyond the per-point floor for levels 0 / 8 / 15 - so {0,15} takes 187 us where {7,8} takes 63, and the
+// launch waits for group 0.  Odd point tiles therefore take the MIRRORED pair ({7-k, 8+k} on the XCD that has {k, 15-k}
+// for the even ones): every XCD then carries (187 + 63) / 2 ... (142 + 122) / 2 = 125-132 us, and its L2 holds four
+// tables (2 of its 4 MiB) instead of two.
+__device__ __forceinline__ int group_level(int group, int j, uint32_t tile) {
+#ifndef HBR_K1_MIRROR
+#define HBR_K1_MIRROR 1
+#endif
+  const bool mirrored = HBR_K1_MIRROR == 2 ? tile >= (gridDim.x / kXcds + 1) / 2 : (HBR_K1_MIRROR == 1 && (tile & 1u));
+  const int g = mirrored ? 7 - group : group;
+  return 8 * j + ((j & 1) ? 7 - g : g);
+}
 
 template <int LAYOUT, int DTYPE>
 __device__ __forceinline__ void store_feat(void* y, uint32_t n, int l, uint32_t N, int64_t stride, float f0, float f1) {

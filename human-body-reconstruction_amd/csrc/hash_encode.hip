@@ -28,10 +28,16 @@ __global__ __launch_bounds__(kFwdThreads) void hash_fwd_kernel(PointSrc ps, uint
   float px, py, pz, nx, ny, nz;
   load_point(ps, n, px, py, pz);
   normalise(g, px, py, pz, nx, ny, nz);
+#ifdef HBR_K1_ONLY_GROUP  // timing-only variant: one XCD group's work alone (profiles/r03_k1_level_costs.txt)
+  if (group != HBR_K1_ONLY_GROUP) return;
+#endif
 
   for (int j = 0; j < levels_per_group; ++j) {
-    const int l = group_level(group, j);
+    const int l = group_level(group, j, tile);
     if (l >= g.L) continue;
+#ifdef HBR_K1_ONLY_LEVEL  // timing-only variant: one level's work alone
+    if (l != HBR_K1_ONLY_LEVEL) continue;
+#endif
     Cell c = locate(nx, ny, nz, g.scale[l]);
     uint32_t rows[8];
     float w[8];
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(kFwdThreads) void hash_bwd_atomic_kernel(PointSrc p
   normalise(g, px, py, pz, nx, ny, nz);
 
   for (int j = 0; j < levels_per_group; ++j) {
-    const int l = group_level(group, j);
+    const int l = group_level(group, j, tile);
     if (l >= g.L) continue;
     float d0, d1;
     load_feat<LAYOUT, DTYPE>(dy, n, l, N, dy_stride, d0, d1);
