@@ -89,7 +89,7 @@ def cpu_baseline(S, mn, sig, total_steps, Rc=4096, budget_s=25.0):
     return out
 
 
-def dropin_leg(dev, batches, mn, sig, S, steps, warmup, total_steps, precision, optim=None):
+def dropin_leg(dev, batches, mn, sig, S, steps, warmup, total_steps, precision, optim=None, T=2 ** 16):
     """The boundary BASELINE.json's north_star names: the loop body of /root/reference/train_hash2.py:211-234 written
     against the drop-in classes - Volume_Renderer.vol_render under autocast, MSE(Cr)+MSE(Cf), loss.backward(),
     torch.optim.Adam(lr .05) on encoder.Embedding_list / AdamW(lr .005) on DataParallel(MLP_3D), two
@@ -101,7 +101,7 @@ def dropin_leg(dev, batches, mn, sig, S, steps, warmup, total_steps, precision, 
     optim = optim or torch.optim
     from hbr_amd.trainer import build_default_model
     from hbr_amd.vol_renderer import Volume_Renderer
-    enc, denc, mlp = build_default_model(mn, sig, dev, seed=0)                                  # train_hash2.py:120-127
+    enc, denc, mlp = build_default_model(mn, sig, dev, T=T, seed=0)                             # train_hash2.py:120-127
     nerf = torch.nn.DataParallel(mlp, device_ids=[dev.index])
     vr = Volume_Renderer(H=800, W=800, K=torch.eye(3), near=2.0, far=6.0, device=dev, Pos_encode=enc, Dir_encode=denc,
                          max_dim=2 ** 10, sigma_val=sig.to(dev), mu=mn.to(dev))                  # :124-126
@@ -132,6 +132,100 @@ def dropin_leg(dev, batches, mn, sig, S, steps, warmup, total_steps, precision, 
     return (time.perf_counter() - t0) / steps * 1e3, float(loss.detach())
 
 
+def _ev_ms(pairs):
+    return sum(a.elapsed_time(b) for a, b in pairs) / max(1, len(pairs))
+
+
+def hierarchical_leg(dev, batches, mn, sig, S, steps, warmup, total_steps, precision, T=2 ** 16):
+    """The other training entry point: the reference's loop body with --hierarchical (train_hash2.py:34,220): the coarse
+    pass's weights drive hbr_hierarchical_resample, and a second vol_render pass evaluates the 2S merged per-ray depths;
+    loss = MSE(Cr) + MSE(Cf).  Drop-in classes + autograd + hbr_amd.optim, same resident batches.  Returns ms/step and
+    the HIP-event spans of its three phases (render = both passes, backward, optimiser)."""
+    import torch
+    import hbr_amd.optim as fused_optim
+    from hbr_amd.trainer import build_default_model
+    from hbr_amd.vol_renderer import Volume_Renderer
+    enc, denc, mlp = build_default_model(mn, sig, dev, T=T, seed=0)
+    nerf = torch.nn.DataParallel(mlp, device_ids=[dev.index])
+    vr = Volume_Renderer(H=800, W=800, K=torch.eye(3), near=2.0, far=6.0, device=dev, Pos_encode=enc, Dir_encode=denc,
+                         max_dim=2 ** 10, sigma_val=sig.to(dev), mu=mn.to(dev))
+    oe = fused_optim.Adam(enc.Embedding_list.parameters(), lr=0.05)
+    om = fused_optim.AdamW(nerf.parameters(), lr=0.005)
+    se = torch.optim.lr_scheduler.CosineAnnealingLR(oe, T_max=total_steps, eta_min=1e-4)
+    sm = torch.optim.lr_scheduler.CosineAnnealingLR(om, T_max=total_steps, eta_min=1e-4)
+    crit = torch.nn.MSELoss()
+    spans = {"render_2_passes": [], "backward": [], "optimiser": []}
+
+    def step(i, timed):
+        o, d, dn, gt = batches[i % len(batches)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
+        if timed: ev[0].record()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=precision == "bf16"):
+            Cr, Cf, _ = vr.vol_render(nerf, d, o, num_samples=S, update_mask=False, dir_norm=dn, hierarchical=True)
+            loss = crit(Cr, gt) + crit(Cf, gt)
+        if timed: ev[1].record()
+        loss.backward()
+        if timed: ev[2].record()
+        oe.step(); om.step(); se.step(); sm.step()
+        om.zero_grad(set_to_none=True); oe.zero_grad(set_to_none=True)
+        if timed:
+            ev[3].record()
+            for k, name in enumerate(spans):
+                spans[name].append((ev[k], ev[k + 1]))
+        return loss
+
+    for i in range(warmup):
+        step(i, False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = step(i, i % 4 == 0)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return ms, {k: _ev_ms(v) for k, v in spans.items()}, float(loss.detach())
+
+
+def render_leg(dev, batch, enc, mlp, precision, fdt, reps, S=256):
+    """The image-write loop's body (train_hash2.py:277-292): 16 000-ray chunks at 256 samples under no_grad -
+    hbr_render_fwd (direction encoding, K1, K3, K5 enqueued by one library call).  Returns ms per chunk through that call,
+    and the HIP-event times of the same four kernels issued one by one."""
+    import torch
+    from hbr_amd import ops
+    from hbr_amd._lib import PLANAR
+    o, d, dn, _ = batch
+    R = o.shape[0]
+    geom, tables = enc.geometry(), enc.stacked_tables()
+    flat, _ = mlp.flat_params()
+    t = ops.strat_sample(2.0, 6.0, S, dev, seed=7, offset=0)
+    with torch.no_grad():
+        for _ in range(3):
+            ops.render_fwd(geom, tables, flat, o, d, t, dn, precision=precision, feat_dtype=fdt)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.render_fwd(geom, tables, flat, o, d, t, dn, precision=precision, feat_dtype=fdt)
+        e1.record()
+        torch.cuda.synchronize()
+        whole = e0.elapsed_time(e1) / reps
+        spans = {"dir_encode": [], "hash_fwd": [], "mlp_fwd": [], "composite_fwd": []}
+        for _ in range(reps):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+            ev[0].record()
+            pe = ops.dir_encode(d, 4)
+            ev[1].record()
+            feat = ops.hash_encode_fwd(geom, tables, rays=(o, d, t), layout=PLANAR, dtype=fdt)
+            ev[2].record()
+            out = ops.mlp_fwd(feat, PLANAR, pe, S, flat, precision)
+            ev[3].record()
+            ops.composite_fwd(t, out.data_ptr(), 4, out.data_ptr() + 12, 4, dn, R, S, want_wts=False)
+            ev[4].record()
+            for k, name in enumerate(spans):
+                spans[name].append((ev[k], ev[k + 1]))
+        torch.cuda.synchronize()
+    return whole, {k: _ev_ms(v) for k, v in spans.items()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,6 +234,7 @@ def main():
     ap.add_argument("--rays", type=int, default=16000, help="rays per rank per step (train_hash2.py:27)")
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--hash-size", type=int, default=16, help="log2 of the rows per level (train_hash2.py:36 --hash_size; BASELINE config 2: 16)")
     ap.add_argument("--feat-dtype", default="auto", choices=["auto", "f32", "bf16"],
                     help="storage of the feature / feature-gradient buffers between the hash and MLP kernels (auto: the MLP precision)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong", "both"],
@@ -208,7 +303,8 @@ def main():
             # composited on a fine quadrature (a consistent radiance field, so the loss/PSNR of the run mean something)
             o, d, dn, gt = synthetic.scene_rays(R, seed=1000 + rank * pool + b, device=dev)
             batches.append(tuple(a.contiguous() for a in (o, d, dn.reshape(-1), gt)))
-        enc, denc, mlp = build_default_model(mn, sig, dev, seed=0)  # same init on every rank (replicated parameters)
+        T = 2 ** args.hash_size
+        enc, denc, mlp = build_default_model(mn, sig, dev, T=T, seed=0)  # same init on every rank (replicated parameters)
         prec = _lib.BF16 if args.precision == "bf16" else _lib.F32
         fdt = prec if args.feat_dtype == "auto" else (_lib.BF16 if args.feat_dtype == "bf16" else _lib.F32)
         total_steps = 4000 * 1000  # train_hash2.py:156-157: epochs * len(loader) (1000 epochs x 4000 batches of the 64M lego rays)
@@ -226,7 +322,7 @@ def main():
             torch.cuda.synchronize()
 
         if args.only_dropin:
-            ms, dl = dropin_leg(dev, batches, mn, sig, S, args.steps, args.warmup, total_steps, args.precision)
+            ms, dl = dropin_leg(dev, batches, mn, sig, S, args.steps, args.warmup, total_steps, args.precision, T=T)
             print(json.dumps({"dropin_ms_per_step": ms, "dropin_value": R * S / (ms * 1e-3), "loss": dl, "steps": args.steps}), flush=True)
             return
         # world > 1 and no explicit HBR_OVERLAP_COMM: the trainer measures the one-collective and the staged step on
@@ -282,15 +378,18 @@ def main():
                     issue = json.load(f)
             except Exception:
                 pass
+            # the stored counters belong to one build of the kernels: say so when the running sources are not that build
+            live_sha = _lib.kernel_source_sha()
+            stale = {"traffic": pmc.get("kernel_source_sha") != live_sha, "issue": issue.get("kernel_source_sha") != live_sha}
             # HBM bytes a launch cannot avoid at this size: K1 tables once + the feature write; K2 the feature-gradient read,
             # the gradient-table write and the normalised coordinates (written once); K3/K4 their streams
-            compulsory = {"hash_fwd": 16 * 65536 * 8 + N * 32 * fb, "hash_bwd": N * 32 * fb + 16 * 65536 * 8 + N * 12,
+            compulsory = {"hash_fwd": 16 * T * 8 + N * 32 * fb, "hash_bwd": N * 32 * fb + 16 * T * 8 + N * 12,
                           "mlp_fwd": N * 32 * fb + N * 16, "mlp_bwd": 2 * N * 32 * fb + 2 * N * 16}
             for k, r in roofs.items():
                 r["frac"] = r["achieved"] / r["peak"]
                 r["kernel"] = k
                 r["avg_ms"] = kern[k]
-                same_shape = (R, S, fb) == (16000, 128, 2)  # the stored profiles are of the default configuration
+                same_shape = (R, S, fb, T) == (16000, 128, 2, 2 ** 16)  # the stored profiles are of the default configuration
                 r["traffic"] = pmc.get(k) if same_shape else None
                 r["traffic_source"] = pmc.get("source", "profiles/pmc_traffic.json") + " (stored rocprofv3 --pmc profile of this configuration, not measured in this run)" if r["traffic"] else None
                 if r["bound"] == "hbm":
@@ -305,16 +404,33 @@ def main():
                         r["frac_note"] = "above 1: the byte model is not a ceiling for a cache-resident table; see hbm_frac and roofline_issue"
                 if same_shape and k in issue:
                     r["roofline_issue"] = issue[k]
+                    r["roofline_issue_stale"] = stale["issue"]
+                if r["traffic"]:
+                    r["traffic_source_stale"] = stale["traffic"]
         dominant = max(kern, key=kern.get) if kern else None
 
         # ---- the reference's own loop on the drop-in classes (the boundary north_star names), same batches ---------
         dropin = None
         if rank == 0 and world == 1 and not args.no_dropin:
-            ms, dl = dropin_leg(dev, batches, mn, sig, S, args.steps, args.warmup, total_steps, args.precision)
+            ms, dl = dropin_leg(dev, batches, mn, sig, S, args.steps, args.warmup, total_steps, args.precision, T=T)
             import hbr_amd.optim as fused_optim
-            ms2, _ = dropin_leg(dev, batches, mn, sig, S, args.steps, args.warmup, total_steps, args.precision, optim=fused_optim)
+            ms2, _ = dropin_leg(dev, batches, mn, sig, S, args.steps, args.warmup, total_steps, args.precision, optim=fused_optim, T=T)
             dropin = dict(ms_per_step=ms, value=R * S / (ms * 1e-3), loss=dl, ms_fused_optim=ms2)
             print(f"[bench] drop-in loop: {ms:.3f} ms/step (torch.optim), {ms2:.3f} ms/step (hbr_amd.optim)", file=sys.stderr, flush=True)
+
+        # ---- the other two entry points (N = 1 only): --hierarchical training and the image-write render -----------
+        extras = {}
+        if rank == 0 and world == 1 and not args.no_dropin:
+            hs = max(8, args.steps // 2)
+            hms, hspans, hloss = hierarchical_leg(dev, batches, mn, sig, S, hs, max(3, args.warmup // 2), total_steps, args.precision, T=T)
+            rms, rspans = render_leg(dev, batches[0], enc, mlp, prec, fdt, reps=max(5, args.steps // 5))
+            extras = {"hierarchical_ms_per_step": hms, "hierarchical_value": R * 2 * S / (hms * 1e-3), "hierarchical_phases_ms": hspans,
+                      "hierarchical_note": f"train_hash2.py --hierarchical on the drop-in classes + hbr_amd.optim: coarse pass of {S} + fine pass of {2 * S} "
+                                           "merged depths per ray, loss = MSE(Cr) + MSE(Cf); value counts the fine pass's 2S samples per ray",
+                      "render_ms_per_16k_rays_256": rms * 16000 / R, "render_value": R * 256 / (rms * 1e-3), "render_kernels_ms": rspans,
+                      "render_note": f"hbr_render_fwd on {R} rays x 256 samples under no_grad (the image-write loop body, train_hash2.py:277-292); "
+                                     "render_kernels_ms: the same four kernels issued one by one"}
+            print(f"[bench] hierarchical loop: {hms:.3f} ms/step; render 16k x 256: {rms:.3f} ms", file=sys.stderr, flush=True)
 
         # ---- CPU baseline: the oracle (a port of the reference's PyTorch-CPU path) on a bounded sample ---------
         cpu = None
@@ -328,11 +444,11 @@ def main():
                 "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
                 "dtype": "bf16" if prec == _lib.BF16 else "f32", "data": "synthetic",
-                "config": {"workload": "lego-shaped synthetic scene, hash encoding L=16 F=2 T=2^16 N_min=16 N_max=2048, "
+                "config": {"workload": f"lego-shaped synthetic scene, hash encoding L=16 F=2 T=2^{args.hash_size} N_min=16 N_max=2048, "
                                        f"{R} rays/rank x {S} samples/ray ({scaling} scaling), MLP 32-64-64-16 / 39-64-64-3, fp32 tables, "
                                        f"{'bf16' if prec == _lib.BF16 else 'fp32'} MLP (MFMA), "
                                        f"{'bf16' if fdt == _lib.BF16 else 'fp32'} feature/feature-gradient buffers, Adam+AdamW+cosine",
-                           "rays_per_rank": R, "samples_per_ray": S, "global_rays": R * world, "levels": 16, "table_rows": 2 ** 16,
+                           "rays_per_rank": R, "samples_per_ray": S, "global_rays": R * world, "levels": 16, "table_rows": T,
                            "parallelism": f"ray-sharded dp{world}, 1 all-reduce/step" if world > 1 else "single GPU"},
                 "loss": loss,
                 "roofline": roofs.get(dominant), "roofline_hash_lookup": roofs.get("hash_fwd"), "kernels": roofs or None,
@@ -346,6 +462,7 @@ def main():
                 "dropin_ms_per_step": dropin and dropin["ms_per_step"], "dropin_value": dropin and dropin["value"],
                 # the same loop with `from hbr_amd.optim import Adam, AdamW` in place of torch.optim's (same interface, fused kernel)
                 "dropin_fused_optim_ms_per_step": dropin and dropin["ms_fused_optim"],
+                **extras,
             }
             print(json.dumps(line), flush=True)
         return line

@@ -63,6 +63,22 @@ class HbrError(RuntimeError):
     pass
 
 
+def kernel_source_sha() -> str:
+    """sha256 over the kernel sources (csrc/*.hip, csrc/*.h, csrc/build.sh, include/hbr_hip.h), sorted by name: what a
+    stored counter profile (profiles/pmc_*.json) was taken on, independent of link-time details of the .so."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(_HERE)
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) +
+                   [os.path.join(_HERE, "csrc", "build.sh"), os.path.join(root, "include", "hbr_hip.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build(verbose: bool = False) -> str:
     """Compile csrc/*.hip for gfx950 into libhbr_hip.so (hipcc cross-compiles without a GPU)."""
     r = subprocess.run(["bash", os.path.join(_HERE, "csrc", "build.sh")], capture_output=True, text=True)

@@ -32,15 +32,16 @@ def _axis_linspace64(lo: float, hi: float, res: int, idx: torch.Tensor) -> torch
     return torch.where(idx == res - 1, torch.full_like(y, float(hi)), y)
 
 
-def grid_coordinates(min_bound, max_bound, res: int, device, start: int = 0, stop: Optional[int] = None) -> torch.Tensor:
-    """Rows [start, stop) of the reference's [res^3, 3] lattice as fp32 values of fp16-rounded positions
+def grid_coordinates(min_bound, max_bound, res: int, device, start: int = 0, stop: Optional[int] = None,
+                     index: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Rows [start, stop) - or the rows `index` (int64 flat indices) - of the reference's [res^3, 3] lattice as fp32 values of fp16-rounded positions
     (nerf2mesh.py:30-40): float64 `np.linspace` per axis, `np.meshgrid(x, y, z)` with its default 'xy' indexing - so
     the flat index is (iy*res + ix)*res + iz - stacked, cast to float16.  Built on `device` from the flat index, so
     a 512^3 lattice (1.3e8 points, 3.2 GB as float64 on the host in the reference) never exists as a whole."""
     mn = np.asarray(torch.as_tensor(min_bound).detach().cpu(), dtype=np.float64).reshape(-1)
     mx = np.asarray(torch.as_tensor(max_bound).detach().cpu(), dtype=np.float64).reshape(-1)
     stop = res ** 3 if stop is None else min(stop, res ** 3)
-    i = torch.arange(start, stop, dtype=torch.int64, device=device)
+    i = torch.arange(start, stop, dtype=torch.int64, device=device) if index is None else index.to(device=device, dtype=torch.int64)
     iz, ix, iy = i % res, (i // res) % res, i // (res * res)
     grid = torch.stack([_axis_linspace64(mn[0], mx[0], res, ix), _axis_linspace64(mn[1], mx[1], res, iy),
                         _axis_linspace64(mn[2], mx[2], res, iz)], dim=1)

@@ -27,6 +27,9 @@ def free_workspaces(device=None) -> int:
     for key in list(_ws_cache):
         if dev is None or torch.device(key[1]) == dev:
             n += _ws_cache.pop(key).numel()
+    for key in list(_mlp_image):  # the packing records point into those buffers: the allocator may hand the block to someone else
+        if dev is None or torch.device(key[0]) == dev:
+            del _mlp_image[key]
     return n
 
 
@@ -62,6 +65,23 @@ def _workspace(kind, nbytes: int, device) -> torch.Tensor:
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
+
+
+def _written(*tensors) -> None:
+    """Tell autograd / the caches keyed on `_version` that a kernel wrote these tensors through raw pointers (the fused
+    optimiser's p / m / v, the occupancy grid): saved-tensor checks and `_image_key` / `_mask_is_trivial` then see the
+    change exactly as they would after a torch in-place op."""
+    for t in tensors:
+        if t is None:
+            continue
+        torch.autograd.graph.increment_version(t)
+        # version counters are per tensor FAMILY: a parameter re-pointed with `p.data = flat[a:b]` (MLP_3D.flat_params)
+        # shares flat's memory but not its counter, so the packed-image records are also dropped by ADDRESS RANGE
+        lo = t.data_ptr()
+        hi = lo + t.numel() * t.element_size()
+        for key, (_, (pptr, _, n)) in list(_mlp_image.items()):
+            if pptr < hi and lo < pptr + 4 * n:
+                del _mlp_image[key]
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
@@ -180,8 +200,13 @@ def hash_encode_bwd(geom: HashGeom, dy: torch.Tensor, dtables: torch.Tensor, x: 
         nws = lib().hbr_hash_bwd_workspace_bytes_min(R * S, geom.L, geom.T, geom.F, algo)
     if algo == 3:  # coordinates of the previous call must still be there: never (re)allocate for this call
         ws = _ws_cache.get(("hash_bwd", dy.device, _stream()))
-        if ws is None or ws.numel() < nws:
+        nmin = lib().hbr_hash_bwd_workspace_bytes_min(R * S, geom.L, geom.T, geom.F, algo)
+        if ws is None or ws.numel() < nmin:
             raise HbrError("algo 3 re-uses the previous hash_encode_bwd call's workspace on this stream: none (large enough) exists")
+        if ws.numel() < nws:
+            # the preceding algo-2 call ran with the minimal workspace (its full one was over _MAX_SCATTER_WS) while this
+            # call's smaller level range would fit the cap: same mode here - coordinates re-used, float-atomic flush
+            nws = nmin
     else:
         ws = _workspace("hash_bwd", nws, dy.device) if nws else None
     if dy_absmax is not None:
@@ -211,6 +236,10 @@ def dir_encode(x: torch.Tensor, num_freq: int) -> torch.Tensor:
 def _feat_desc(feat: torch.Tensor, layout: int):
     dtype = _elem_dtype(feat, "feat")
     if layout == PLANAR:
+        # the MLP kernels read 16 levels x 2 features per point (train_hash2.py:107,127): a planar buffer of another
+        # level count would be read past its end
+        if feat.dim() != 3 or feat.shape[0] != 16 or feat.shape[2] != 2 or not feat.is_contiguous():
+            raise HbrError(f"planar MLP features must be a contiguous [16, N, 2] buffer, got {tuple(feat.shape)}")
         N = feat.shape[1]
         stride = 0
     else:
@@ -380,6 +409,7 @@ def occupancy_update(grid: torch.Tensor, mu, sigma_val: float, alpha: torch.Tens
     m = (C.c_float * 3)(*[float(v) for v in mu])
     check(lib().hbr_occupancy_update(_ptr(x), _ptr(o), _ptr(d), _ptr(t), R, S, alpha.data_ptr(), grid.data_ptr(), _ptr(tmp_arr), G, m,
                                      float(sigma_val), ws.data_ptr(), ws.numel(), _stream()), "hbr_occupancy_update")
+    _written(grid, tmp_arr)
 
 
 def hierarchical_resample(weights: torch.Tensor, z_vals: torch.Tensor, n_samples: int, tn: float, tf: float,
@@ -470,12 +500,15 @@ def adam_step_multi(segments: Sequence[dict]):
         segs[k] = _lib.AdamSegment(a["p"].data_ptr(), a["g"].data_ptr(), a["m"].data_ptr(), a["v"].data_ptr(), a["p"].numel(), a["lr"],
                                    a["beta1"], a["beta2"], a["eps"], a["weight_decay"], a["step"], a.get("grad_scale", 1.0))
     check(lib().hbr_adam_step_multi(len(segments), segs, _stream()), "hbr_adam_step_multi")
+    for a in segments:
+        _written(a["p"], a["m"], a["v"])
 
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     require_gpu(p)
     check(lib().hbr_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
                               weight_decay, step, grad_scale, _stream()), "hbr_adam_step")
+    _written(p, m, v)
 
 
 def _dir_norm_arg(dir_norm, R, device):
@@ -600,7 +633,7 @@ class RenderFn(torch.autograd.Function):
         else:
             x, rays = (o[:, None, :] + d[:, None, :] * t[:, :, None]).reshape(-1, 3).contiguous(), None
         feat = hash_encode_fwd(geom, stacked, x=x, rays=rays, layout=PLANAR, dtype=feat_dtype)
-        out = mlp_fwd(feat, PLANAR, pe, S, flat, precision, keep=keep, image_ready=None)  # keep: occupancy mask [N] or None (all kept)
+        out = mlp_fwd(feat, PLANAR, pe, S, flat, precision, keep=keep, image_ready=None if num_freq == 4 else False)  # keep: occupancy mask [N] or None (all kept)
         Cr, wts = composite_fwd(t, out.data_ptr(), 4, out.data_ptr() + 12, 4, dn, R, S)
         ctx.save_for_backward(o, d, t, pe, feat, out, flat)  # flat: see MlpFn
         ctx.x, ctx.keep = x, keep
@@ -625,7 +658,7 @@ class RenderFn(torch.autograd.Function):
         n_pad = (n_tab + flat.numel() + 3) // 4 * 4
         gbuf = torch.empty(n_pad, dtype=torch.float32, device=o.device)
         dtab, dflat = gbuf[:n_tab].view(g.L, g.T, g.F), gbuf[n_tab:n_tab + flat.numel()]
-        amax = torch.empty(16, dtype=torch.float32, device=o.device) if g.L == 16 else None
+        amax = torch.empty(16, dtype=torch.float32, device=o.device)  # K4's per-level max |d feat| -> K2's fixed-point scale (L == 16: vol_render checks)
         dfeat = mlp_bwd(feat, PLANAR, pe, S, flat, ctx.precision, d_out, dflat, absmax_out=amax, image_ready=None, overwrite=True)
         rays = None if ctx.x is not None else (o, d, t)
         hash_encode_bwd(g, dfeat, dtab, x=ctx.x, rays=rays, layout=PLANAR, dy_absmax=amax, overwrite=True)

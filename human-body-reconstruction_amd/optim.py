@@ -147,17 +147,14 @@ class _FusedAdam(torch.optim.Optimizer):
 
     @staticmethod
     def _flat_grads(ps, fast):
-        """One flat view over the gradients if they are laid out exactly like the parameters (what ops.RenderFn hands
-        back and AccumulateGrad adopts), else None."""
-        g0 = ps[0].grad
-        base = g0.data_ptr()
-        if base % 16 or g0.dtype != torch.float32:
+        """One flat view over the gradients if they are laid out exactly like the parameters IN ONE STORAGE (what
+        ops.RenderFn hands back and AccumulateGrad adopts), else None.  `_consecutive` checks the storage as well as the
+        addresses: separately allocated gradients (p.grad.clone(), a regulariser's gradient that reached AccumulateGrad
+        first) can sit back to back in the caching allocator's arena without sharing one."""
+        if any(p.grad.numel() != p.numel() for p in ps):
             return None
-        for p, off in zip(ps, fast[3]):
-            g = p.grad
-            if g.data_ptr() != base + off or not g.is_contiguous():
-                return None
-        return torch.as_strided(g0, (fast[0].numel(),), (1,))
+        flat = _consecutive([p.grad for p in ps])
+        return flat if flat is not None and flat.numel() == fast[0].numel() else None
 
     @staticmethod
     def _unaligned(seg):

@@ -40,6 +40,9 @@ class HashNeRFTrainer:
                  weight_decay_mlp: float = 0.01, precision: int = BF16, feat_dtype: Optional[int] = None, num_freq: int = 4,
                  process_group=None, scatter_algo: int = 0, overlap_comm: bool = False, split_scatter: Optional[bool] = None,
                  seed: int = 0):
+        if encoder.L * encoder.F != 32 or encoder.E != 0:
+            raise NotImplementedError("HashNeRFTrainer drives the train_hash2.py:107,120,127 model: L=16 levels x F=2 features into "
+                                      f"MLP_3D's 32 inputs; got L={encoder.L}, F={encoder.F}, E={encoder.E}")
         self.enc, self.mlp = encoder, mlp
         self.near, self.far, self.S = float(near), float(far), int(num_samples)
         self.total_steps = int(total_steps)
@@ -118,6 +121,11 @@ class HashNeRFTrainer:
         if not (self.world > 1 or (self.always_reduce and torch.distributed.is_initialized())) or self.geom.L < 2:
             return {}
         res, dev = {}, self.tables.device
+        # The measurement runs real optimiser steps: snapshot parameters, moments and the step counter (the cosine
+        # schedule's position and the depth jitter's Philox offset) and put them back, so that a run tuned with
+        # `--overlap_comm auto` trains exactly the trajectory of `on` / `off` with the same seed.
+        self._bind_parameters()
+        snap = (self.tables.clone(), self.flat.clone(), self.m.clone(), self.v.clone(), self.step_count, self.last_loss)
         for name, split in (("single", False), ("staged", True)):
             self.split_scatter = split
             for i in range(2):  # workspaces, RCCL channels for this message size
@@ -131,6 +139,9 @@ class HashNeRFTrainer:
             dt = torch.tensor([(time.perf_counter() - t0) / steps * 1e3], dtype=torch.float64, device=dev)
             torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX, group=self.pg)
             res[name + "_ms_per_step"] = float(dt.item())
+        with torch.no_grad():
+            self.tables.copy_(snap[0]); self.flat.copy_(snap[1]); self.m.copy_(snap[2]); self.v.copy_(snap[3])
+        self.step_count, self.last_loss = snap[4], snap[5]
         self.split_scatter = res["staged_ms_per_step"] < res["single_ms_per_step"]
         self.overlap_comm = self.split_scatter
         res["chosen"] = "staged" if self.split_scatter else "single"
@@ -173,7 +184,7 @@ class HashNeRFTrainer:
         # No memset of the 8 MiB gradient buffer: K4 and K2 WRITE their outputs (`overwrite`; where K2 runs a path that
         # can only accumulate, ops zeroes that slice itself).  The padding behind the MLP block is never written.
         # K4 also reports max |d feat| per level: K2's fixed-point scale, without K2 re-reading the buffer for it
-        amax = self._amax if g.L == 16 else None
+        amax = self._amax  # (L == 16: checked in __init__)
         # (image_ready: the workspace still holds the weight fragments this step's mlp_fwd packed from self.flat)
         dfeat = self._timed("mlp_bwd", lambda: ops.mlp_bwd(feat, PLANAR, pe, S, self.flat, self.precision, d_out, self.g_mlp,
                                                            absmax_out=amax, image_ready=True, overwrite=True))

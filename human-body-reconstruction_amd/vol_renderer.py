@@ -93,6 +93,9 @@ class Volume_Renderer():
             raise NotImplementedError("hbr_amd.Volume_Renderer accelerates the hash path only: Pos_encode=hbr_amd HashEncoder, "
                                       "Dir_encode=hbr_amd PositionalEncoder(3, num_freq=4), model=hbr_amd MLP_3D; the vanilla "
                                       "positional-encoding NeRF of train.py is out of scope")
+        if enc.L * enc.F + enc.E != 32 or enc.E != 0:
+            raise NotImplementedError("the fused render path is built for the train_hash2.py:107,120 encoder (L=16 levels x F=2 features, "
+                                      f"E=0 extra columns: the MLP's 32 inputs); got L={enc.L}, F={enc.F}, E={enc.E}")
         if denc.d_model != 3 or denc.max_seq_len != 4:
             raise NotImplementedError("direction encoder must be PositionalEncoder(d_model=3, num_freq=4) (train_hash2.py:46,121)")
         if not rays_d.is_cuda:

@@ -74,8 +74,8 @@ def run_seed(ref_dir: str, seed: int, steps: int, eval_every: int, out: str, thr
     ref = MG.import_reference(ref_dir)
     mn, sig, batches, test = scene()
     tables0, u, params0 = seeded_inputs(seed, steps)
-    for _ in range(perturb_ulps):  # sensitivity study: every initial table entry moved to the next fp32 value (1 ulp ~ 1e-11)
-        tables0 = np.nextafter(tables0, np.float32(np.inf))
+    for _ in range(abs(perturb_ulps)):  # sensitivity study: every initial table entry moved to the next fp32 value (1 ulp ~ 1e-11); a negative count moves them down
+        tables0 = np.nextafter(tables0, np.float32(np.inf if perturb_ulps > 0 else -np.inf))
     enc = MG.build_encoder(ref, tables0, 2048.0, 16, mn.numpy(), float(sig))
     denc = ref.encoder.PositionalEncoder(3, 4)
     nerf = torch.nn.DataParallel(MG.build_mlp(ref, params0))          # train_hash2.py:127 (no GPU: calls the module)

@@ -101,3 +101,64 @@ def test_one_launch_per_group_and_fallbacks():
         ops.adam_step_multi = real
     with pytest.raises(NotImplementedError):
         fused.Adam(enc.Embedding_list.parameters(), lr=0.05, weight_decay=0.1)
+
+
+def test_adjacent_but_separately_allocated_gradients_take_the_per_tensor_path():
+    """gradients that sit back to back in memory WITHOUT sharing a storage (the caching allocator's arena
+    hands out 512-byte-multiple blocks side by side) must not be taken for one flat buffer: the flat view would run
+    past the first gradient's storage.  Built deterministically: views of one arena, each re-wrapped as its own
+    storage-sized tensor via from_blob-like slicing is not possible in torch, so the separate storages are real
+    allocations checked for adjacency; if the allocator did not place them adjacently the test still checks the result."""
+    import hbr_amd.optim as fused
+    from hbr_amd import ops
+    from hbr_amd.optim import _consecutive
+    n = 4096  # 16 KiB per tensor: a multiple of 512 B, so the small-block pool lays fresh allocations out back to back
+    torch.cuda.empty_cache()
+    buf = torch.zeros(4 * n, device=DEV)
+    ps = [torch.nn.Parameter(buf[i * n:(i + 1) * n]) for i in range(4)]  # consecutive views of ONE buffer
+    torch.manual_seed(0)
+    grads = [torch.randn(n, device=DEV) for _ in range(4)]               # four storages of their own
+    adjacent = all(grads[i + 1].data_ptr() == grads[i].data_ptr() + 4 * n for i in range(3))
+    for p, g in zip(ps, grads):
+        p.grad = g
+    assert _consecutive([p.grad for p in ps]) is None                     # separate storages, whatever their addresses
+    calls = []
+    real = ops.adam_step_multi
+    ops.adam_step_multi = lambda segs: (calls.append(len(segs)), real(segs))[1]
+    try:
+        opt = fused.Adam(ps, lr=0.01)
+        opt.step()                                                        # used to raise setStorage ... out of bounds when adjacent
+    finally:
+        ops.adam_step_multi = real
+    assert calls == [4], (calls, adjacent)
+    want = [torch.nn.Parameter(torch.zeros(n, device=DEV)) for _ in range(4)]
+    for p, g in zip(want, grads):
+        p.grad = g.clone()
+    torch.optim.Adam(want, lr=0.01).step()
+    for a, b in zip(ps, want):
+        assert torch.allclose(a, b, rtol=0, atol=1e-7)
+    print("gradients were adjacent in the arena:", adjacent)
+
+
+def test_fused_optimiser_step_bumps_versions_and_invalidates_the_weight_image():
+    """the fused optimisers write p / m / v through raw pointers; the version counters must move as after a
+    torch in-place op, so that ops' record of the packed weight image (keyed on _version) goes stale."""
+    import hbr_amd.optim as fused
+    from hbr_amd import ops
+    (o, d, dn, gt), enc, nerf, vr = _world(seed=5)
+    mlp = nerf.module
+    flat, _ = mlp.flat_params()
+    om = fused.AdamW(nerf.parameters(), lr=0.005)
+    t = torch.linspace(2.0, 6.0, 32, device=DEV)
+    Cr, _, _ = vr.vol_render(nerf, d, o, num_samples=32, t=t, dir_norm=dn, hierarchical=False)
+    ((Cr - gt) ** 2).mean().backward()
+    assert any(v[1][0] == flat.data_ptr() for v in ops._mlp_image.values())   # the render packed an image of `flat`
+    v0 = [p._version for p in nerf.parameters()]
+    om.step()
+    assert all(p._version > a for p, a in zip(nerf.parameters(), v0))
+    # (the parameters alias `flat` through `.data`, which does not share version counters: the record is dropped by address)
+    assert not any(v[1][0] == flat.data_ptr() for v in ops._mlp_image.values())
+    Cr2, _, _ = vr.vol_render(nerf, d, o, num_samples=32, t=t, dir_norm=dn, hierarchical=False)
+    assert any(v[1][0] == flat.data_ptr() for v in ops._mlp_image.values())
+    ops.free_workspaces()
+    assert not ops._mlp_image

@@ -579,3 +579,81 @@ def test_integration_md_ctypes_stub_runs_verbatim():
         g, gr = weights[l].grad.cpu(), ref_t[l].grad
         assert float((g - gr).abs().max()) <= 1e-4 * float(gr.abs().max()) + 1e-9, l
 
+
+
+@pytest.mark.parametrize("L", [8, 12])
+def test_k2_other_level_counts_vs_oracle_and_absmax_handoff(ops, L):
+    """K2 at L = 8 and 12 (the fused step itself is L = 16 only - the MLP kernels read 32 features,
+    and vol_render / HashNeRFTrainer refuse another encoder, checked below): the LDS kernels against the oracle, and a
+    caller-supplied per-level max |dy| (K4's hand-off) gives the same BITS as K2's own absmax pass."""
+    from hbr_amd._lib import PLANAR
+    R, S, T = 1024, 64, 2 ** 14
+    N = R * S
+    o, d, _, _ = ref_cpu.synthetic_rays(R, seed=60 + L)
+    mn, mx, sig = ref_cpu.bbox_mu_sigma(o, d)
+    sc = ref_cpu.level_scales(16, 2048.0, L)
+    geom = ops.HashGeom(tuple(float(v) for v in sc), tuple(float(v) for v in mn), float(sig), T, 2)
+    t = ref_cpu.strat_jitter_to_t(2.0, 6.0, S, torch.rand(S, generator=torch.Generator().manual_seed(61)))
+    rng = np.random.default_rng(62 + L)
+    dy_bf = torch.from_numpy((rng.standard_normal((N, L * 2)) * 10.0 ** rng.uniform(-4, 0, (N, 1))).astype(np.float32)).bfloat16()
+    dy_planar = dy_bf.reshape(N, L, 2).permute(1, 0, 2).contiguous().to(DEV)
+    pts = ref_cpu.sample_points(o, d, t).reshape(-1, 3)
+    ref = ref_cpu.hash_encode_backward(pts, dy_bf.float(), sc, mn, sig, T).numpy()
+    rays = (o.to(DEV), d.to(DEV), t.to(DEV))
+    got = torch.zeros((L, T, 2), device=DEV)
+    ops.hash_encode_bwd(geom, dy_planar, got, rays=rays, layout=PLANAR, algo=2)
+    assert np.allclose(got.cpu().numpy(), ref, rtol=1e-4, atol=1e-6 * np.abs(ref).max())
+    amax = dy_planar.float().abs().amax(dim=(1, 2))
+    again = torch.zeros((L, T, 2), device=DEV)
+    ops.hash_encode_bwd(geom, dy_planar, again, rays=rays, layout=PLANAR, algo=2, dy_absmax=amax)
+    assert torch.equal(again, got)
+    # the fused routes refuse an encoder that does not feed the MLP's 32 inputs
+    from hbr_amd.hash_encoding import HashEncoder
+    from hbr_amd.test_hash import MLP_3D
+    from hbr_amd.trainer import HashNeRFTrainer
+    from hbr_amd.vol_renderer import Volume_Renderer
+    from hbr_amd.encoder import PositionalEncoder
+    enc = HashEncoder(N_max=2048.0, N_min=16, L=L, T=T, F=2, dim=3, mu=mn.to(DEV), sigma=sig.to(DEV), device=DEV)
+    mlp = MLP_3D(num_sig=2, num_col=2, L=16, F=2, d_view=24).to(DEV)
+    with pytest.raises(NotImplementedError):
+        HashNeRFTrainer(enc, mlp, num_samples=S)
+    vr = Volume_Renderer(H=8, W=8, K=torch.eye(3), near=2.0, far=6.0, device=DEV, Pos_encode=enc, Dir_encode=PositionalEncoder(3, 4), sigma_val=sig, mu=mn)
+    with pytest.raises(NotImplementedError):
+        vr.vol_render(mlp, rays[1], rays[0], num_samples=S, t=rays[2], update_mask=False, hierarchical=False)
+    with pytest.raises(Exception):  # a planar buffer of another level count never reaches the MLP kernels
+        ops.mlp_fwd(torch.zeros((L, 64, 2), device=DEV), PLANAR, torch.zeros((1, 24), device=DEV), 64, mlp.flat_params()[0], 0)
+
+
+@pytest.mark.parametrize("log2T", [17, 19])
+def test_k2_large_tables_vs_oracle(ops, log2T):
+    """train_hash2.py:36 --hash_size above the README's 16 (19 is the Instant-NGP default the flag reaches): the LDS
+    kernels on 131 072 points against the oracle, bit-identical re-run, and the two flushes / the global-atomics kernel
+    beside it."""
+    from hbr_amd._lib import PLANAR
+    R, S, L, T = 1024, 128, 16, 2 ** log2T
+    N = R * S
+    o, d, t, mn, sig, sc, geom = _scene(ops, R, S, T, seed=71)
+    rng = np.random.default_rng(72)
+    dy_bf = torch.from_numpy((rng.standard_normal((N, L * 2)) * 10.0 ** rng.uniform(-5, 0, (N, 1))).astype(np.float32)).bfloat16()
+    dy_planar = dy_bf.reshape(N, L, 2).permute(1, 0, 2).contiguous().to(DEV)
+    pts = ref_cpu.sample_points(o, d, t).reshape(-1, 3)
+    ref = ref_cpu.hash_encode_backward(pts, dy_bf.float(), sc, mn, sig, T).numpy()
+    rays = (o.to(DEV), d.to(DEV), t.to(DEV))
+    runs = []
+    for _ in range(2):
+        got = torch.zeros((L, T, 2), device=DEV)
+        ops.hash_encode_bwd(geom, dy_planar, got, rays=rays, layout=PLANAR, algo=2)
+        runs.append(got)
+    assert torch.equal(runs[0], runs[1])
+    g = runs[0].cpu().numpy()
+    assert np.allclose(g, ref, rtol=1e-4, atol=1e-6 * np.abs(ref).max())
+    assert not np.any((g != 0) & (ref == 0))
+    assert np.all((g != 0) | (np.abs(ref) < 1e-10 * np.abs(ref).max()))
+    for kw in (dict(algo=2, deterministic=False), dict(algo=1)):
+        alt = torch.zeros((L, T, 2), device=DEV)
+        ops.hash_encode_bwd(geom, dy_planar, alt, rays=rays, layout=PLANAR, **kw)
+        assert np.allclose(alt.cpu().numpy(), ref, rtol=1e-4, atol=1e-6 * np.abs(ref).max()), kw
+    # overwrite mode leaves the same bits in a dirty buffer
+    dirty = torch.full((L, T, 2), 7.0, device=DEV)
+    ops.hash_encode_bwd(geom, dy_planar, dirty, rays=rays, layout=PLANAR, algo=2, overwrite=True)
+    assert torch.equal(dirty, runs[0])

@@ -11,6 +11,9 @@ OUT="$ROOT/gpurun_out/$TAG"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
+# what the counters below are taken on: the kernel sources' fingerprint (bench.py flags stored counters whose fingerprint
+# is not the running library's: traffic_source_stale) and the library file's own hash
+python3 -c "import sys; sys.path.insert(0, '$ROOT'); from hbr_amd import _lib; import hashlib; print(_lib.kernel_source_sha()); print(hashlib.sha256(open(_lib.LIB_PATH,'rb').read()).hexdigest()[:16])" > "$OUT/kernel_source_sha.txt"
 timeout -k 10 300 python3 "$ROOT/bench.py" --steps 50 --warmup 10 > "$OUT/bench.json" 2> "$OUT/bench.err"
 Q="--no-cpu-baseline --no-dropin"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o run -- python3 "$ROOT/bench.py" --steps 25 --warmup 5 $Q > "$OUT/kt.log" 2>&1

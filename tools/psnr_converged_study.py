@@ -18,6 +18,10 @@ test = tuple(a.to(DEV) for a in test)
 t_eval = torch.linspace(MP.NEAR, MP.FAR, MP.S, device=DEV)
 seeds = [int(s) for s in os.environ.get("SEEDS", ",".join(str(int(s)) for s in g["seeds"])).split(",")]
 configs = os.environ.get("CONFIGS", "fused-bf16,fused-bf16-f32feat,fused-fp32,dropin-bf16,dropin-fp32").split(",")
+# PERTURBS: the initial tables moved by that many fp32 ulps (the reference's own self-noise runs use the same moves);
+# a config ending in "-algo1" scatters with global float atomics (no fixed-point quantum) instead of the LDS kernels
+perturbs = [int(v) for v in os.environ.get("PERTURBS", "0").split(",")]
+OUT_JSON = os.environ.get("OUT_JSON", "")
 
 
 def model(tables0, params0):
@@ -29,15 +33,17 @@ def model(tables0, params0):
     return enc, denc, mlp
 
 
-def run(seed, cfg):
+def run(seed, cfg, ulps=0):
     tables0, u, params0 = MP.seeded_inputs(seed, steps)
+    for _ in range(abs(ulps)):
+        tables0 = np.nextafter(tables0, np.float32(np.inf if ulps > 0 else -np.inf))
     ts = torch.stack([ref_cpu.strat_jitter_to_t(MP.NEAR, MP.FAR, MP.S, torch.from_numpy(u[k])) for k in range(steps)]).to(DEV)
     enc, denc, mlp = model(tables0, params0)
     curve = []
     if cfg.startswith("fused"):
         prec = F32 if "fp32" in cfg else BF16
         tr = HashNeRFTrainer(enc, mlp, near=MP.NEAR, far=MP.FAR, num_samples=MP.S, total_steps=steps, precision=prec,
-                             feat_dtype=F32 if "f32feat" in cfg else None)
+                             feat_dtype=F32 if "f32feat" in cfg else None, scatter_algo=1 if cfg.endswith("-algo1") else 0)
         for k in range(steps):
             tr.step(*batches[k % MP.NB], t=ts[k])
             if k + 1 in ev:
@@ -63,13 +69,20 @@ def run(seed, cfg):
     return np.array(curve)
 
 
+import json
+results = {}
 for cfg in configs:
-    ds = []
-    for i, seed in enumerate(int(s) for s in g["seeds"]):
-        if seed not in seeds: continue
-        c = run(seed, cfg); ref = g["psnr"][i]
-        q = len(ev) // 4
-        ds.append(c[-1] - ref[-1])
-        print(f"{cfg:20s} seed {seed}: ref {ref[-1]:.3f}  hip {c[-1]:.3f}  delta {ds[-1]:+.3f} | step {ev[q]}: {c[q]-ref[q]:+.3f}  step {ev[2*q]}: {c[2*q]-ref[2*q]:+.3f}  step {ev[3*q]}: {c[3*q]-ref[3*q]:+.3f} | tail span {c[int(len(c)*.8):].max()-c[int(len(c)*.8):].min():.3f}", flush=True)
-    ds = np.array(ds)
-    print(f"{cfg:20s} mean delta {ds.mean():+.3f}  std {ds.std():.3f}  max|d| {np.abs(ds).max():.3f}", flush=True)
+    for ulps in perturbs:
+        ds = []
+        gseeds = [int(s) for s in g["seeds"]]
+        for seed in seeds:
+            c = run(seed, cfg, ulps); ref = g["psnr"][gseeds.index(seed)] if seed in gseeds else np.full(len(ev), np.nan)
+            q = len(ev) // 4
+            ds.append(c[-1] - ref[-1])
+            results.setdefault(cfg, {}).setdefault(str(seed), {})[str(ulps)] = [float(v) for v in c]
+            print(f"{cfg:22s} ulps {ulps:+d} seed {seed}: ref {ref[-1]:.3f}  hip {c[-1]:.3f}  delta {ds[-1]:+.3f} | step {ev[q]}: {c[q]-ref[q]:+.3f}  step {ev[2*q]}: {c[2*q]-ref[2*q]:+.3f}  step {ev[3*q]}: {c[3*q]-ref[3*q]:+.3f} | tail span {c[int(len(c)*.8):].max()-c[int(len(c)*.8):].min():.3f}", flush=True)
+        ds = np.array(ds)
+        print(f"{cfg:22s} ulps {ulps:+d} mean delta {ds.mean():+.3f}  std {ds.std():.3f}  max|d| {np.abs(ds).max():.3f}", flush=True)
+        if OUT_JSON:
+            with open(OUT_JSON, "w") as f:
+                json.dump({"eval_steps": ev, "final_psnr_curves": results}, f)

@@ -69,6 +69,11 @@ with open(os.path.join(dst, f"{tag}_pmc_hbm.csv"), "w") as f:
         traffic[k] = tot
         f.write(f"{k},TOTAL,,,,{tot:.0f}\n")
 traffic["source"] = f"profiles/{tag}_pmc_hbm.csv"
+sha_file = os.path.join(src, "kernel_source_sha.txt")
+shas = open(sha_file).read().split() if os.path.exists(sha_file) else []
+if not shas:
+    raise SystemExit(f"{sha_file} is missing: tools/profile_round.sh writes it - refusing to store counters that cannot be tied to a kernel build")
+traffic["kernel_source_sha"], traffic["lib_sha"] = shas[0], shas[1]
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 
 # ---- issue-side: what bounds the two hash kernels (neither is HBM-bound: VERDICT r2 weak #2) -------------------------
@@ -121,6 +126,7 @@ for span, pat in (("hash_bwd", "hash_scatter_kernel"), ("hash_fwd", "hash_fwd_ke
                    note="SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / kernel cycles")
     issue[span] = rec
 issue["source"] = f"profiles/{tag}_issue_counters.csv"
+issue["kernel_source_sha"], issue["lib_sha"] = shas[0], shas[1]
 json.dump(issue, open(os.path.join(dst, "pmc_issue.json"), "w"), indent=1)
 
 line = [l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")][-1]
