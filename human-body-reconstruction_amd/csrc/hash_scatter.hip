@@ -44,7 +44,20 @@ constexpr uint32_t kRoundMagicHi = 0x43380000u;      // its high word (the low w
 constexpr int kAbsBlocks = 512;                // partial maxima per level (absmax kernels' grid.x)
 constexpr int kDenseLevels = 6;                // dense levels are a prefix of the levels; at most this many
 constexpr int kDenseCap = 10000;               // vertices of a dense table with both features (160 000 B of LDS)
-constexpr int64_t kDenseMaxT = 1LL << 18;      // the per-level int64 row table of the dense path is T*16 B
+constexpr int64_t kDenseMaxT = 1LL << 22;      // the per-level int64 row table of the dense path is T*16 B (cleared and re-read per call)
+// Tables of 16 or more slices per level (train_hash2.py:36 --hash_size 18 and up) take the MASKED form of the
+// hashed branch: a small kernel first records, per (level, slice, 64-point step), which points have a corner in the
+// slice; a slice owner then loads its chunk's coordinates as before but VISITS only the flagged points, compacted
+// through a per-wave LDS ring - 4 (1 - (1 - 1/spl)^4) / spl of the points instead of all of them (12 % at spl = 32).
+// The unmasked form is linear in T: 0.52 / 0.94 / 1.65 / 4.24 / 7.44 ms at T = 2^16 .. 2^20 (profiles/r04_k2_vs_T.txt);
+// masked: 1.31 / 1.90 / 3.28 ms at 2^18 .. 2^20.  What is left is bandwidth, not arithmetic: every slice owner still
+// STREAMS its chunk's coordinates and dy (16 B per point) to pick its 12 % - 64 owners per level at 2^19 = 33 GB of
+// L2 -> L1 traffic per call; a 128-byte line holds ten points, so gathering only the flagged ones would fetch 3/4 of
+// the lines anyway, and routing (x, y, z, dy) payloads to the owners through memory is 6 GB of HBM traffic.
+constexpr int kMaskMinSlices = 16, kMaskMaxSlices = 256;  // (measured at 8 slices, T = 2^17: 0.973 ms masked, 0.935 unmasked)
+constexpr int kRing = 128;                     // entries (16 B) of a wave's ring: a step adds <= 64, a pop takes 64
+constexpr uint32_t kMaskedLdsBytes = kSliceBytes + (kLdsBwdThreads / 64) * kRing * 16;  // 160 KiB: the CU's whole LDS
+static_assert(kMaskedLdsBytes <= 160 * 1024, "LDS of a gfx950 CU");
 constexpr int kDenseStripesPerWg = 64;         // 64 Ki points per dense workgroup (measured at N = 2M: 16 -> 0.663 ms, 32 -> 0.633, 64 -> 0.617, 128 -> 0.629)
 
 // ------------------------------------------------------------------------------------------------
@@ -371,6 +384,48 @@ struct SegDy {
 };
 
 // ------------------------------------------------------------------------------------------------
+// slice-membership masks (tables of kMaskMinSlices or more slices per level)
+// ------------------------------------------------------------------------------------------------
+// masks[l][slice][stripe][w] bit i = "entry (stripe, w, i) of the coordinate block - the point the scatter kernel's lane i
+// visits at step w of that stripe - has at least one of its eight corners in rows [slice * 16384, (slice + 1) * 16384) of
+// level l".  One workgroup per stripe, wave w = step w; a lane ORs its bit into its wave's [spl] words in LDS (rows come
+// from corner_rows, the same cell arithmetic the visit uses, any T), then the words leave as plain 8-byte stores.  Points
+// beyond N (the last stripe's padding) are never flagged; dense levels and all-zero / non-finite levels are skipped (the
+// scatter kernel does not sweep them either).
+template <bool POW2>
+__global__ __launch_bounds__(kLdsBwdThreads) void slice_mask_kernel(uint32_t N, HashGeom g, int spl, int fixbits, int dense_levels,
+                                                                     const float* __restrict__ xnorm, const Meta* __restrict__ meta,
+                                                                     unsigned long long* __restrict__ masks) {
+  __shared__ unsigned long long wm[kLdsBwdThreads / 64][kMaskMaxSlices];
+  const uint32_t s = blockIdx.x, stripes = gridDim.x;
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const float* q = xnorm + ((size_t)s * 1024u + threadIdx.x) * 3;
+  const float nx = q[0], ny = q[1], nz = q[2];
+  const bool live = s * 1024u + lane * kSeg + wv < N;
+  const unsigned long long bit = 1ull << lane;
+  for (int l = 0; l < g.L; ++l) {
+    const LevelPlan plan = level_plan(meta, g, l, fixbits, dense_levels);
+    if (plan.dense || plan.fs.state != 1) continue;  // uniform over the workgroup
+    for (int i = lane; i < spl; i += 64) wm[wv][i] = 0ull;
+    __syncthreads();
+    if (live) {
+      const Cell c = locate(nx, ny, nz, g.scale[l]);
+      uint32_t rows[8];
+      corner_rows<POW2>(g, c, rows);
+      uint32_t prev = 0xffffffffu;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t sl = rows[k] >> kSliceLog2;
+        if (sl != prev) atomicOr(&wm[wv][sl], bit);  // x-neighbours almost always share their slice
+        prev = sl;
+      }
+    }
+    __syncthreads();
+    for (int i = lane; i < spl; i += 64) masks[(((size_t)l * spl + i) * stripes + s) * kSeg + wv] = wm[wv][i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // hashed-slice kernel
 // ------------------------------------------------------------------------------------------------
 // One workgroup = (level, 16384-row slice, feature f, chunk of points).  Splitting the two features of a row over
@@ -379,12 +434,13 @@ struct SegDy {
 // Flush: `slabs` != nullptr -> the workgroup converts its slice to fp32 and stores it (plain, contiguous) into
 // slab [chunk][l][f][row]; slab_reduce_kernel then sums the chunks in a fixed order.  nullptr -> contiguous global
 // float atomics straight into dtables (no extra memory, but the fp32 sum of the chunk partials is order-dependent).
-template <bool POW2, int LAYOUT, int DTYPE>
-__device__ __forceinline__ void hashed_slice_body(const uint32_t b, unsigned long long* __restrict__ acc /* LDS [kSliceRows] */,
+template <bool POW2, int LAYOUT, int DTYPE, bool MASKED>
+__device__ __forceinline__ void hashed_slice_body(const uint32_t b, unsigned long long* __restrict__ acc /* LDS [kSliceRows] (+ the rings) */,
                                                   uint32_t N, const void* __restrict__ dy, int64_t dy_stride, const HashGeom& g,
                                                   float* __restrict__ dtables, int slices_per_level, int chunks, int fixbits,
                                                   int dense_levels, const float* __restrict__ xnorm,
-                                                  const Meta* __restrict__ meta, float* __restrict__ slabs) {
+                                                  const Meta* __restrict__ meta, float* __restrict__ slabs,
+                                                  const unsigned long long* __restrict__ masks) {
   // block -> (level, slice, feature, chunk); chunk varies fastest so the blocks of one slice start together and, with
   // a multiple of 8 chunks, chunk c of every (level, slice, feature) lands on XCD c % 8: its coordinates and dy are
   // re-read from that XCD's L2
@@ -525,8 +581,76 @@ __device__ __forceinline__ void hashed_slice_body(const uint32_t b, unsigned lon
       }
     }
   };
-  if (nonneg) sweep(std::true_type{});
-  else sweep(std::false_type{});
+  // MASKED: the same stripes, but only the points slice_mask_kernel flagged for this slice are visited.  A wave loads the
+  // coordinates of eight steps at a time (coalesced, every lane), pushes the flagged lanes' (x, y, z, dy) into its ring in
+  // LDS at tail + (flagged lanes below me) - the step's 64-bit mask is wave-uniform, so the test is two ANDs against the
+  // lane's own bit and the rank two v_mbcnt - and visits 64 ring entries whenever that many are waiting.  LDS operations
+  // of one wave execute in order, so the ring needs no barrier.  Order of visits differs from the unmasked sweep; the
+  // integer sums do not depend on it.
+  auto sweep_masked = [&](auto nonneg_tag) {
+    float4* ring = (float4*)((char*)acc + kSliceBytes) + wv * kRing;
+    uint32_t head = 0, tail = 0;  // wave-uniform
+    const uint32_t stripes = (N + 1023u) / 1024u;
+    const unsigned long long* mrow = masks + ((size_t)l * slices_per_level + slice) * (size_t)stripes * kSeg;
+    const uint32_t bit_lo = lane < 32u ? 1u << lane : 0u, bit_hi = lane >= 32u ? 1u << (lane - 32u) : 0u;
+    auto pop = [&](uint32_t count) {  // count <= 64 entries from the head; lanes beyond it visit the origin with dy = 0 (adds 0)
+      float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lane < count) e = ring[(head + lane) & (kRing - 1)];
+      head += count;
+      visit(nonneg_tag, e.x, e.y, e.z, e.w);
+    };
+    for (uint32_t s = s_begin + wv; s < s_end; s += kLdsBwdThreads / 64) {
+      const unsigned long long mine = mrow[(size_t)s * kSeg + (lane & (kSeg - 1))];  // lane m holds step m's mask
+      const uint32_t m_lo = (uint32_t)mine, m_hi = (uint32_t)(mine >> 32);
+      const float* q = xnorm + ((size_t)s * 1024u + lane) * 3;
+      const uint32_t n0 = s * 1024u + lane * kSeg;
+      const bool vec = vec_ok && s * 1024u + 1024u <= N;  // uniform
+      SegDy<DTYPE> seg;
+      if (vec) seg.load(dy, l, N, n0);
+      else {
+#pragma unroll
+        for (int k = 0; k < SegDy<DTYPE>::kVecs; ++k) seg.v[k] = make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int g8 = 0; g8 < kSeg; g8 += 8) {
+        float cx[8], cy[8], cz[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {  // eight steps' coordinates in flight
+          const float* qq = q + (g8 + k) * 64 * 3;
+          cx[k] = qq[0]; cy[k] = qq[1]; cz[k] = qq[2];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int m = g8 + k;
+          const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)m_lo, m), hi = (uint32_t)__builtin_amdgcn_readlane((int)m_hi, m);
+          if ((lo | hi) == 0u) continue;  // uniform
+          if (((lo & bit_lo) | (hi & bit_hi)) != 0u) {
+            float dv;
+            if (vec) {
+              dv = seg.pick(m, f, psel);
+            } else {
+              const uint2 raw = load_feat_raw<LAYOUT, DTYPE>(dy, n0 + m, l, N, dy_stride);  // a flagged point is < N
+              float d0, d1;
+              decode_feat<DTYPE>(raw, d0, d1);
+              dv = f ? d1 : d0;
+            }
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+            ring[(tail + rank) & (kRing - 1)] = make_float4(cx[k], cy[k], cz[k], dv);
+          }
+          tail += (uint32_t)__builtin_popcount(lo) + (uint32_t)__builtin_popcount(hi);
+          if (tail - head >= 64u) pop(64u);
+        }
+      }
+    }
+    if (tail != head) pop(tail - head);
+  };
+  if constexpr (MASKED) {
+    if (nonneg) sweep_masked(std::true_type{});
+    else sweep_masked(std::false_type{});
+  } else {
+    if (nonneg) sweep(std::true_type{});
+    else sweep(std::false_type{});
+  }
   __syncthreads();
 
   if (slab) {
@@ -657,17 +781,18 @@ __device__ __forceinline__ void dense_body(const uint32_t b, unsigned long long*
 // 49 us worth of instructions when launched on their own).
 // (waves_per_eu 4: the LDS allows one 16-wave workgroup per CU anyway, so take the 128 VGPRs that leaves - at the
 // default heuristic the dense walk's sixteen running sums spilled to scratch.)
-template <bool POW2, int LAYOUT, int DTYPE>
+template <bool POW2, int LAYOUT, int DTYPE, bool MASKED>
 __global__ __launch_bounds__(kLdsBwdThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void hash_scatter_kernel(
     uint32_t N, const void* __restrict__ dy, int64_t dy_stride, HashGeom g, float* __restrict__ dtables, int slices_per_level,
     int chunks, int dchunks, uint32_t dense_blocks, int fixbits, int dense_levels, const float* __restrict__ xnorm,
-    const Meta* __restrict__ meta, float* __restrict__ slabs, unsigned long long* __restrict__ dslab) {
+    const Meta* __restrict__ meta, float* __restrict__ slabs, unsigned long long* __restrict__ dslab,
+    const unsigned long long* __restrict__ masks) {
   extern __shared__ unsigned long long acc[];
   if (blockIdx.x < dense_blocks)
     dense_body<LAYOUT, DTYPE>(blockIdx.x, acc, N, dy, dy_stride, g, dchunks, fixbits, dense_levels, xnorm, meta, dslab);
   else
-    hashed_slice_body<POW2, LAYOUT, DTYPE>(blockIdx.x - dense_blocks, acc, N, dy, dy_stride, g, dtables, slices_per_level, chunks,
-                                           fixbits, dense_levels, xnorm, meta, slabs);
+    hashed_slice_body<POW2, LAYOUT, DTYPE, MASKED>(blockIdx.x - dense_blocks, acc, N, dy, dy_stride, g, dtables, slices_per_level,
+                                                   chunks, fixbits, dense_levels, xnorm, meta, slabs, masks);
 }
 
 // dense vertex tables -> rows: one thread per (vertex, feature) of a dense level sums the chunks' integers and adds
@@ -773,6 +898,21 @@ static int lds_chunks(int64_t N, int spl) {
   return chunks;
 }
 static int lds_slices(int64_t T) { return (int)((T + kSliceRows - 1) / kSliceRows); }
+// the masked form of the hashed branch (slice_mask_kernel + ring visits) pays from sixteen slices per level
+static bool lds_masked(int spl) { return spl >= kMaskMinSlices && spl <= kMaskMaxSlices; }
+// Chunks of the masked form: every (level, slice, feature) owner scans the masks of ALL its chunk's stripes whatever it
+// visits, and each chunk costs a 64 KiB slab per owner - so as few chunks as still give ~1500 workgroups (six rounds of
+// the 256 CUs at 16 levels): 3 at 16 slices, 2 at 32, 1 from 64.  Depends on N and T only, like lds_chunks.  (No
+// limit on the points per workgroup is needed: the fixed-point scale is derived from N, so no sum over any subset of a
+// launch's contributions can overflow.)
+static int lds_chunks_masked(int64_t N, int spl) {
+  constexpr int kTargetBlocks = 1536, kRefLevels = 16;
+  int chunks = (kTargetBlocks + kRefLevels * spl * 2 - 1) / (kRefLevels * spl * 2);
+  const int max_chunks = (int)((N + kLdsBwdThreads - 1) / kLdsBwdThreads);
+  if (chunks > max_chunks) chunks = max_chunks;
+  return chunks < 1 ? 1 : chunks;
+}
+static int hashed_chunks(int64_t N, int spl) { return lds_masked(spl) ? lds_chunks_masked(N, spl) : lds_chunks(N, spl); }
 static int dense_chunks(int64_t N) {
   const int64_t stripes = (N + 1023) / 1024;
   int64_t c = (stripes + kDenseStripesPerWg - 1) / kDenseStripesPerWg;
@@ -787,7 +927,7 @@ static int fix_bits_for(int64_t N) {
 // workspace: [normalised coordinates, 3 floats per point, whole stripes][Meta][partial maxima][partial boxes]
 //            | min ends here |  [int64 row tables of the dense levels][dense slabs][chunk slabs]
 struct Workspace {
-  int64_t xnorm, meta, abs_part, bounds_part, min_total, g64, dslab, slabs, total;
+  int64_t xnorm, meta, abs_part, bounds_part, min_total, g64, dslab, slabs, masks, total;
   int dense_levels;  // levels the dense path can take at all (0: disabled for this T)
 };
 static Workspace workspace(int64_t N, int L, int64_t T) {
@@ -803,7 +943,9 @@ static Workspace workspace(int64_t N, int L, int64_t T) {
   w.g64 = w.min_total;
   w.dslab = up(w.g64 + (int64_t)w.dense_levels * T * 2 * 8);
   w.slabs = up(w.dslab + (int64_t)w.dense_levels * dense_chunks(N) * 4 * kDenseCap * 8);
-  w.total = w.slabs + (int64_t)lds_chunks(N, lds_slices(T)) * L * 2 * T * 4;
+  const int spl = lds_slices(T);
+  w.masks = up(w.slabs + (int64_t)hashed_chunks(N, spl) * L * 2 * T * 4);
+  w.total = w.masks + (lds_masked(spl) ? (int64_t)L * spl * stripes * kSeg * 8 : 0);  // slice-membership masks [L][spl][stripes][16]
   return w;
 }
 
@@ -827,7 +969,8 @@ template <bool POW2, int LAYOUT, int DTYPE>
 static int launch_lds(hipStream_t st, uint32_t N, const void* dy, int64_t stride, const HashGeom& g, float* dtables, char* ws,
                       const Workspace& w, bool full, bool overwrite, bool g64_cleared) {
   const int spl = lds_slices(g.T);
-  const int chunks = lds_chunks(N, spl);
+  const bool masked = full && lds_masked(spl);  // (the masks live behind the slabs: full workspace only)
+  const int chunks = masked ? lds_chunks_masked(N, spl) : lds_chunks(N, spl);
   const int fixbits = fix_bits_for(N);
   const float* xnorm = (const float*)(ws + w.xnorm);
   const Meta* meta = (const Meta*)(ws + w.meta);
@@ -838,12 +981,23 @@ static int launch_lds(hipStream_t st, uint32_t N, const void* dy, int64_t stride
   const int dchunks = dense_chunks(N);
   const uint32_t dense_blocks = (uint32_t)(dl * dchunks * 2);
   if (dl > 0 && !g64_cleared && hipMemsetAsync(g64, 0, (size_t)dl * g.T * 16, st) != hipSuccess) return HBR_ELAUNCH;
-  auto kern = hash_scatter_kernel<POW2, LAYOUT, DTYPE>;
-  const int lds = dl > 0 ? 2 * kDenseCap * 8 : kSliceRows * 8;
-  static_assert(2 * kDenseCap * 8 >= kSliceRows * 8, "the dense table is the larger LDS user");
-  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kDenseCap * 8) != hipSuccess) return HBR_ELAUNCH;
-  hipLaunchKernelGGL(kern, dim3(dense_blocks + (uint32_t)(g.L * spl * 2 * chunks)), dim3(kLdsBwdThreads), lds, st, N, dy, stride, g, dtables,
-                     spl, chunks, dchunks, dense_blocks, fixbits, dl, xnorm, meta, slabs, dslab);
+  static_assert(2 * kDenseCap * 8 >= kSliceRows * 8 && kMaskedLdsBytes >= 2 * kDenseCap * 8, "LDS users: slice < dense table < slice + rings");
+  const uint32_t grid = dense_blocks + (uint32_t)(g.L * spl * 2 * chunks);
+  if (masked) {
+    unsigned long long* masks = (unsigned long long*)(ws + w.masks);
+    const uint32_t stripes = (N + 1023u) / 1024u;
+    hipLaunchKernelGGL((slice_mask_kernel<POW2>), dim3(stripes), dim3(kLdsBwdThreads), 0, st, N, g, spl, fixbits, dl, xnorm, meta, masks);
+    auto kern = hash_scatter_kernel<POW2, LAYOUT, DTYPE, true>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaskedLdsBytes) != hipSuccess) return HBR_ELAUNCH;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kLdsBwdThreads), kMaskedLdsBytes, st, N, dy, stride, g, dtables, spl, chunks, dchunks,
+                       dense_blocks, fixbits, dl, xnorm, meta, slabs, dslab, (const unsigned long long*)masks);
+  } else {
+    auto kern = hash_scatter_kernel<POW2, LAYOUT, DTYPE, false>;
+    const int lds = dl > 0 ? 2 * kDenseCap * 8 : kSliceRows * 8;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kDenseCap * 8) != hipSuccess) return HBR_ELAUNCH;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kLdsBwdThreads), lds, st, N, dy, stride, g, dtables, spl, chunks, dchunks, dense_blocks,
+                       fixbits, dl, xnorm, meta, slabs, dslab, (const unsigned long long*)nullptr);
+  }
   if (dl > 0)
     hipLaunchKernelGGL((dense_scatter_kernel<POW2>), dim3((4 * kDenseCap + 31) / 32, (uint32_t)dl), dim3(256), 0, st, g, dchunks,
                        fixbits, dl, meta, (const unsigned long long*)dslab, g64);

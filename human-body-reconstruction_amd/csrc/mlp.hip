@@ -317,28 +317,46 @@ __device__ __forceinline__ void dense(const char* img, int fbase, const float* b
   }
 }
 
-// Packed 16-bit helpers on bf16 pairs (one VGPR = two activations).  Inline asm: hipcc 7.2 scalarises 8-wide `short`
-// vectors and miscompiled the element-wise update of a bit-cast vector in a loop (round 1), and for `fmaxf(x, 0)` it
-// emits a canonicalising `v_max_f32 x, x, x` in front of the max - 2 instructions per activation, 256 per tile.
+// Packed 16-bit helpers on bf16 pairs (one VGPR = two activations).  For `fmaxf(x, 0)` hipcc emits a canonicalising
+// `v_max_f32 x, x, x` in front of the max - 2 instructions per activation, 256 per tile - and it scalarises 8-wide `short`
+// vectors; on 2-wide vectors `__builtin_elementwise_max` / `min` select v_pk_max_i16 / v_pk_max_u16 / v_pk_min_u16 directly.
 //   ReLU of a bf16 = signed 16-bit max with 0 (negative floats are negative integers; -0 -> +0).
 //   "was the ReLU output positive" = its bits are non-zero: min(bits, 1) is 0 / 1, and a 16-bit multiply by it keeps
 //   or clears a gradient's bits.
+// Round 4: these were inline asm until the round-3 two-tile experiment's "first tile of every wave is wrong" was traced
+// (tools/dev/mfma_operand_hazard_scan.py): gfx950 needs 2 wait states between a VALU write of a VGPR and an MFMA reading
+// it as an operand; hipcc pads that pair only when it KNOWS the writer is a VALU instruction.  An `asm` statement is
+// opaque to it - and, not being volatile, free to be scheduled one slot ahead of the consuming MFMA, which is what the
+// experiment's prologue forward got (nine `v_pk_max_i16 vN ; s_waitcnt ; v_mfma ... vN` triples: stale operands whenever
+// the s_waitcnt did not happen to stall).  The shipped kernels carried 23 such triples too (K3: 3 per planar
+// instantiation; K4: 2), masked only by their LDS waits.  Builtins put the hazard back into the compiler's hands;
+// tests/test_lib_abi.py scans the built library's disassembly for any VALU -> MFMA-operand pair closer than 2 slots.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_relu_bf16(uint32_t w) {
-  uint32_t r;
-  asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(w));
-  return r;
+  const s16x2 z = {0, 0};
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, w), z));
 }
 __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
-  uint32_t r;
-  asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
 }
-// (one asm statement for the pair: between two dependent statements hipcc pads an `s_nop 0` - 4 issue cycles at one
-// wave per SIMD - because it cannot see what the second one reads; volatile: see mfma_acc_lds)
+// The mask epilogue stays inline asm: it is slotted word by word behind the owners' asm MFMAs (volatile = pinned in
+// program order relative to them; one statement for the dependent pair - between two statements hipcc pads an `s_nop 0`,
+// 4 issue cycles at one wave per SIMD).  Its outputs are therefore asm-VALU writes: whoever assembles them into MFMA
+// operands calls asm_valu_pad() on the finished fragments first.
 __device__ __forceinline__ uint32_t pk_keep_where_nonzero_ordered(uint32_t grad, uint32_t act, uint32_t ones /* 0x00010001 */) {
   uint32_t r;
   asm volatile("v_pk_min_u16 %0, %2, %3\n\tv_pk_mul_lo_u16 %0, %1, %0" : "=&v"(r) : "v"(grad), "v"(act), "v"(ones));
   return r;
+}
+// Two wait states behind inline-asm VALU writes of the fragments `f[0..N)`, in front of every consumer: the statement
+// takes the fragments as read-write operands, so it is ordered after their producers and before their readers whatever
+// hipcc's scheduler does with the surrounding code.  (8 issue cycles; N <= 4 fragments = 16 VGPR operands per statement.)
+template <int N>
+__device__ __forceinline__ void asm_valu_pad(bf16x8 (&f)[N]) {
+  static_assert(N == 2 || N == 4, "fragments of one or two 32-feature tiles");
+  if constexpr (N == 2) asm volatile("s_nop 1" : "+v"(f[0]), "+v"(f[1]));
+  else asm volatile("s_nop 1" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
 }
 
 // ReLU + re-pack.  No mask is recorded: the backward pass reads the sign back from the packed activations themselves
@@ -1226,6 +1244,7 @@ __device__ __forceinline__ void dense_mask_take(const char* img, int fbase, int 
     for (int f = 0; f < NT * P::S32; ++f) {
       out[f] = PBf16::from_words(ow[4 * f], ow[4 * f + 1], ow[4 * f + 2], ow[4 * f + 3]);
     }
+    asm_valu_pad(out);  // the words came out of asm statements: the next dense's MFMAs read them as operands
   } else {
     dense<P, NT, NK, 0>(img, fbase, nullptr, lane, lofs, dz, a);
     mask_frags<P, NT>(a, h, out);

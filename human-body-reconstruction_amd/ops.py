@@ -15,7 +15,7 @@ from . import _lib
 from ._lib import BF16, EUNSUPPORTED, F32, IMAGE_READY, OVERWRITE, PLANAR, ROWS, HbrError, check, lib, require_gpu
 
 _ws_cache = {}
-_MAX_SCATTER_WS = 1 << 30  # largest K2 workspace allocated for the reproducible (slab) flush; beyond: the minimal one
+_MAX_SCATTER_WS = 4 << 30  # largest K2 workspace allocated for the reproducible (slab) flush (T = 2^20: 0.6 GB, 2^22: 3 GB of 288); beyond: the minimal one
 
 
 def free_workspaces(device=None) -> int:

@@ -119,6 +119,12 @@ class _FusedAdam(torch.optim.Optimizer):
                         segs.append(one)
         for i in range(0, len(segs), 4):
             ops.adam_step_multi(segs[i:i + 4])
+        # the kernel wrote through raw pointers: move every parameter's version counter as torch's in-place update would
+        # (a flat one-launch segment only carries the FIRST tensor's counter)
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is not None:
+                    torch.autograd.graph.increment_version(p)
         return loss
 
     def _fast_views(self, gi, group, ps):

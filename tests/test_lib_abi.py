@@ -152,3 +152,18 @@ def test_helper_geometry_matches_golden():
     mn, mx, _ = ref_cpu.bbox_mu_sigma(o, d, 2.0, 6.0)
     mx2, mn2 = helper.find_bounding_box2([(o, d, dn, None)], 2.0, 6.0)
     assert torch.allclose(mx2, mx) and torch.allclose(mn2, mn)
+
+
+def test_no_valu_write_within_two_slots_of_an_mfma_operand_read(L):
+    """Round 4 (DESIGN 3, K4 "root cause"): gfx950 needs 2 wait states between a VALU write of a VGPR and an MFMA reading
+    it as A / B / C; hipcc pads the pair only when it knows the writer is a VALU instruction - not when it sits inside
+    an `asm` statement.  The round-3 builds carried 23 such pairs (inline-asm v_pk_max_i16 one slot ahead of the
+    consuming v_mfma), masked by LDS waits in the shipped kernels and fatal in the two-tile experiment.  The built
+    library's disassembly must hold none: every MFMA of every kernel is checked."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mfma_scan", os.path.join(ROOT, "tools", "dev", "mfma_operand_hazard_scan.py"))
+    scan = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(scan)
+    total, found = scan.scan_library(L.LIB_PATH)
+    assert total > 5000, f"only {total} MFMAs found: the disassembly did not cover mlp.hip's kernels"
+    assert not found, "\n".join(found[:20])

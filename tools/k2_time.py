@@ -5,7 +5,7 @@ import torch, ref_cpu
 from hbr_amd import ops
 from hbr_amd._lib import PLANAR
 dev = "cuda:0"
-R, S, L, T = 16000, 128, 16, 2 ** 16
+R, S, L, T = int(os.environ.get('K2_RAYS', 16000)), 128, 16, 2 ** int(os.environ.get('K2_LOG2T', 16))
 o, d, dn, gt = ref_cpu.synthetic_rays(R, seed=0)
 mn, mx, sig = ref_cpu.bbox_mu_sigma(o, d)
 sc = ref_cpu.level_scales(16, 2048.0, L)
@@ -23,4 +23,4 @@ for dtype in (torch.float32, torch.bfloat16):
     for _ in range(10):
         ops.hash_encode_bwd(geom, dy, dt, rays=rays, layout=PLANAR, algo=2)
     e1.record(); torch.cuda.synchronize()
-    print(os.environ.get("HBR_LIB", "default"), dtype, f"hash_bwd {e0.elapsed_time(e1) / 10:.4f} ms", flush=True)
+    print(os.environ.get("HBR_LIB", "default"), f"T=2^{os.environ.get('K2_LOG2T', 16)} R={R}", dtype, f"hash_bwd {e0.elapsed_time(e1) / 10:.4f} ms", flush=True)
