@@ -21,7 +21,9 @@ The cosine schedule ends at the horizon, so the run anneals into a plateau.
 Usage (one process per seed, ~50 min each on one thread, then merge):
     PYTHONDONTWRITEBYTECODE=1 python oracle/make_psnr_golden.py --seed 1 --steps 2000 --out /tmp/psnr/s1.npz
     ... --seed 1 --perturb-ulps 1 --save-final /tmp/psnr_p/final_s1.npz --out /tmp/psnr_p/s1.npz      (sensitivity re-run)
-    python oracle/make_psnr_golden.py --merge /tmp/psnr/s*.npz --merge-ulp /tmp/psnr_p/s?.npz    -> tests/golden/g15_converged_psnr.npz
+    ... --seed 1 --perturb-ulps 2 / --perturb-ulps -1 ...                                          (round 4: two more per seed)
+    python oracle/make_psnr_golden.py --merge /tmp/psnr/s*.npz --merge-ulp /tmp/psnr_p/s?.npz /tmp/psnr4/s?_u2.npz /tmp/psnr4/s?_u-1.npz \
+                                      --merge-degenerate /tmp/psnr4/s5_u0.npz                      -> tests/golden/g15_converged_psnr.npz
     cp /tmp/psnr_p/final_s1.npz tests/golden/g15b_trained_weights.npz    (the reference's trained weights + its held-out render)
 """
 from __future__ import annotations
@@ -120,22 +122,40 @@ def run_seed(ref_dir: str, seed: int, steps: int, eval_every: int, out: str, thr
         np.savez_compressed(save_final, **fin)
 
 
-def merge(files, ulp_files=()):
-    """files: the unperturbed runs (one per seed); ulp_files: the same seeds re-run with --perturb-ulps 1 (the reference's
-    own sensitivity to a one-ulp change of its initial tables, stored as psnr_ulp)."""
+def merge(files, ulp_files=(), degenerate_files=()):
+    """files: the unperturbed runs (one per seed); ulp_files: re-runs of the same seeds with every initial table entry moved
+    by +1 / +2 / -1 ... fp32 ulps (--perturb-ulps: the reference's OWN trajectory noise - same inputs up to 1e-11, same
+    code); stored as psnr_self [seed, perturbation, eval] with self_ulps naming the perturbations (psnr_ulp = the +1 row, as
+    round 3 stored it).  degenerate_files: runs of seeds from which the reference itself does not train (kept as evidence,
+    excluded from the statistics: degenerate_seeds / psnr_degenerate)."""
     runs = sorted((np.load(f) for f in files), key=lambda z: int(z["seed"]))
-    ulps = sorted((np.load(f) for f in ulp_files), key=lambda z: int(z["seed"]))
+    seeds = [int(z["seed"]) for z in runs]
     extra = {}
-    if ulps:
-        assert [int(z["seed"]) for z in ulps] == [int(z["seed"]) for z in runs] and all(int(z["perturb_ulps"]) == 1 for z in ulps)
-        assert all(int(z["eval_steps"][-1]) == int(z["steps"]) for z in ulps), "a perturbed run did not finish"
-        extra["psnr_ulp"] = np.stack([z["psnr"] for z in ulps])
+    by = {}
+    for f in ulp_files:
+        z = np.load(f)
+        assert int(z["eval_steps"][-1]) == int(z["steps"]), f"{f}: a perturbed run did not finish"
+        assert int(z["perturb_ulps"]) != 0 and int(z["seed"]) in seeds, f
+        by.setdefault(int(z["perturb_ulps"]), {})[int(z["seed"])] = z["psnr"]
+    if by:
+        order = sorted(by, key=lambda u: (abs(u), -u))  # +1, -1, +2, -2, ...
+        for u in order:
+            assert sorted(by[u]) == seeds, f"perturbation {u:+d} ulps: runs for seeds {sorted(by[u])}, expected {seeds}"
+        extra["self_ulps"] = np.array(order)
+        extra["psnr_self"] = np.stack([np.stack([by[u][s] for u in order]) for s in seeds])
+        if 1 in by:
+            extra["psnr_ulp"] = np.stack([by[1][s] for s in seeds])
+    if degenerate_files:
+        dz = sorted((np.load(f) for f in degenerate_files), key=lambda z: int(z["seed"]))
+        extra["degenerate_seeds"] = np.array([int(z["seed"]) for z in dz])
+        extra["psnr_degenerate"] = np.stack([z["psnr"] for z in dz])
+        extra["degenerate_input_checksum"] = np.array([float(z["input_checksum"]) for z in dz])
     steps = {int(z["steps"]) for z in runs}
     assert len(steps) == 1, "all seeds must share the horizon"
     ev = runs[0]["eval_steps"]
     for z in runs:
         assert int(z["eval_steps"][-1]) == int(z["steps"]), f"seed {int(z['seed'])} did not finish"
-    np.savez(OUT, seeds=np.array([int(z["seed"]) for z in runs]), steps=steps.pop(), eval_steps=ev,
+    np.savez(OUT, seeds=np.array(seeds), steps=steps.pop(), eval_steps=ev,
              psnr=np.stack([z["psnr"] for z in runs]), loss_head=np.stack([z["loss"][:16] for z in runs]),
              loss_tail=np.stack([z["loss"][-64:] for z in runs]),
              input_checksum=np.array([float(z["input_checksum"]) for z in runs]),
@@ -145,8 +165,14 @@ def merge(files, ulp_files=()):
     for i, (s, p) in enumerate(zip(z["seeds"], z["psnr"])):
         n = len(p)
         tail = p[int(n * 0.8):]
-        more = f"; with 1-ulp-moved tables {z['psnr_ulp'][i][-1]:.3f} dB ({z['psnr_ulp'][i][-1] - p[-1]:+.3f})" if "psnr_ulp" in z.files else ""
+        more = ""
+        if "psnr_self" in z.files:
+            more = "; re-runs with the tables moved by " + ", ".join(f"{int(u):+d} ulp: {z['psnr_self'][i][k][-1]:.3f} ({z['psnr_self'][i][k][-1] - p[-1]:+.3f})"
+                                                                      for k, u in enumerate(z["self_ulps"]))
         print(f"seed {s}: final {p[-1]:.3f} dB; last 20% of the horizon spans {tail.max() - tail.min():.3f} dB{more}")
+    if "degenerate_seeds" in z.files:
+        for s, p in zip(z["degenerate_seeds"], z["psnr_degenerate"]):
+            print(f"seed {s} (degenerate - excluded): the reference's held-out PSNR stays at {p[-1]:.3f} dB (max over the run {p.max():.3f})")
     print("wrote", OUT)
 
 
@@ -161,9 +187,10 @@ if __name__ == "__main__":
     ap.add_argument("--perturb-ulps", type=int, default=0)
     ap.add_argument("--save-final", default="")
     ap.add_argument("--merge", nargs="+")
-    ap.add_argument("--merge-ulp", nargs="*", default=[])
+    ap.add_argument("--merge-ulp", nargs="*", default=[], help="the perturbed re-runs (any --perturb-ulps), all seeds of --merge")
+    ap.add_argument("--merge-degenerate", nargs="*", default=[], help="runs of seeds the reference itself does not train from")
     a = ap.parse_args()
     if a.merge:
-        merge(a.merge, a.merge_ulp)
+        merge(a.merge, a.merge_ulp, a.merge_degenerate)
     else:
         run_seed(a.ref, a.seed, a.steps, a.eval_every, a.out, a.threads, a.perturb_ulps, a.save_final)
