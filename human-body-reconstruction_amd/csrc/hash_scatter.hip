@@ -891,6 +891,10 @@ static int lds_chunks(int64_t N, int spl) {
   if (chunks > 8) chunks = (chunks + 4) / 8 * 8;  // a multiple of 8: chunk c of every (level, slice, feature) on XCD c % 8
   const int min_chunks = (kMinBlocks + kRefLevels * spl * 2 - 1) / (kRefLevels * spl * 2);
   if (chunks < min_chunks) chunks = min_chunks;
+  // (Round 4, measured and NOT kept: 5 chunks below 384 Ki points / 8 from there, to turn the 1.5 rounds of 384 workgroups
+  // into full ones - K2 at 2000 / 4000 / 8000 rays 0.126 / 0.186 / 0.313 ms against 0.112 / 0.183 / 0.321: a wave takes whole
+  // stripes, so 50 stripes over 16 waves cost the same four stripe-times as 62, and the dense workgroups are as long as
+  // the hashed ones.)
   const int max_chunks = (int)((N + kLdsBwdThreads - 1) / kLdsBwdThreads);
   if (chunks > max_chunks) chunks = max_chunks;
   if (chunks < 1) chunks = 1;

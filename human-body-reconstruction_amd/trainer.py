@@ -85,6 +85,7 @@ class HashNeRFTrainer:
         self.step_count = 0
         self.last_loss = None
         self.timers = None  # optional dict name -> list[(start_event, end_event)], filled when set by bench.py
+        self.grad_hook = None  # optional callable(flat gradient buffer) run in front of the optimiser (studies: tools/psnr_converged_study.py)
         # the step's small launches folded together: prologue (depths + direction encoding + weight image), compositing +
         # loss + compositing backward, one Adam launch.  HBR_FUSED_SMALL=0: the separate launches (A/B, tests).
         import os
@@ -222,6 +223,8 @@ class HashNeRFTrainer:
             # the one collective of the step
             if self.world > 1 or (self.always_reduce and torch.distributed.is_initialized()):
                 self._timed("allreduce_exposed", lambda: torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM, group=self.pg))
+        if self.grad_hook is not None:
+            self.grad_hook(self.grad)
         # optimiser (dense Adam over every table row, as the reference's torch.optim.Adam does)
         k = self.step_count
         gs = 1.0 / self.world

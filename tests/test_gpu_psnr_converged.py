@@ -10,14 +10,21 @@ What the fixtures show, and what is therefore asserted:
    north star's 0.1 dB, two-sided, where it is well defined.
 2. SAME LOOP, first steps (g15 `loss_head`): the drop-in route's first 16 losses equal the reference's to 1e-3 - the
    training step is the reference's before rounding-level differences have been amplified.
-3. TRAINED TO THE PLATEAU from identical initial parameters, rays and jitter: the final PSNR of this problem is itself
-   sensitive at the 1 dB level - the reference re-run with every initial table entry moved by ONE fp32 ulp (g15
-   `psnr_ulp`) ends -0.2 ... +0.9 dB from its own unperturbed run (mean +0.3, sd 0.35), and the exact-fp32 HIP drop-in
-   route, whose arithmetic differs from the reference's only in summation order, -0.4 ... +1.7 dB.  So no implementation
-   that is not bit-identical can be held to 0.1 dB per trajectory; what is asserted is the one-sided statement that
-   matters - no quality loss: mean over the seeds of (HIP - reference) >= -0.3 dB (measured: fused bf16 +0.65, drop-in
-   bf16 +1.12), every seed within 3 dB, and the HIP curves plateau like the reference's (last 20 % of the horizon moves
-   < 0.2 dB).  The measured table is in BASELINE.md / profiles/r03_psnr_converged.txt.
+3. TRAINED TO THE PLATEAU from identical initial parameters, rays and jitter - TWO-SIDED since round 4.  The final PSNR of
+   this problem is itself sensitive at the 1 dB level: g15 now holds, per seed, the reference's unperturbed run and three
+   re-runs with every initial table entry moved by +1 / -1 / +2 fp32 ulps (~1e-11): they end up to 2.9 dB apart (pooled
+   within-seed sd 0.78 dB; the 15 self-deltas average +0.58 dB, sd 0.86).  So no implementation that is not bit-identical
+   can be held to 0.1 dB per trajectory; what CAN be asserted, and is, for both shipped routes run from the same 5 x 4
+   initialisations:
+     (a) the mean over the seeds of (HIP seed mean - reference seed mean) is within 2 standard errors of zero (paired over
+         the seeds), and - VERDICT r3's formulation - the HIP runs' mean delta against the unperturbed reference runs lies
+         within the reference's own self-delta mean +- 2 SE;
+     (b) the HIP runs of one seed spread no wider than 1.5 x the reference's own (measured: 0.4 x - 0.9 x);
+     (c) every HIP run is within 3 dB of its seed's reference mean and plateaus like the reference's (< 0.25 dB over the
+         last 20 % of the horizon).
+   Seed 5 is a DEGENERATE initialisation: the reference itself never leaves 11.02 dB (`degenerate_seeds`); it is excluded
+   from the statistics, and the HIP path is required to collapse to the same plateau.
+   Measured tables: profiles/r04_psnr_envelope.txt (tools/psnr_envelope.py), DESIGN 4, BASELINE.md.
 """
 import os
 
@@ -33,8 +40,10 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _setup(seed, steps):
+def _setup(seed, steps, ulps=0):
     tables0, u, params0 = MP.seeded_inputs(seed, steps)
+    for _ in range(abs(ulps)):  # the perturbation of oracle/make_psnr_golden.py --perturb-ulps
+        tables0 = np.nextafter(tables0, np.float32(np.inf if ulps > 0 else -np.inf))
     ts = torch.stack([ref_cpu.strat_jitter_to_t(MP.NEAR, MP.FAR, MP.S, torch.from_numpy(u[k])) for k in range(steps)]).to(DEV)
     return tables0, u, params0, ts
 
@@ -81,11 +90,11 @@ def _dropin(world, enc, denc, mlp, steps):
     return nerf, vr, (oe, om, se, sm), torch.nn.MSELoss()
 
 
-def _train_fused(world, seed, steps, eval_steps):
+def _train_fused(world, seed, steps, eval_steps, ulps=0):
     from hbr_amd._lib import BF16
     from hbr_amd.trainer import HashNeRFTrainer
     g, mn, sig, batches, test = world
-    tables0, u, params0, ts = _setup(seed, steps)
+    tables0, u, params0, ts = _setup(seed, steps, ulps)
     enc, denc, mlp = _model(mn, sig, tables0, params0)
     tr = HashNeRFTrainer(enc, mlp, near=MP.NEAR, far=MP.FAR, num_samples=MP.S, total_steps=steps, precision=BF16)
     t_eval = torch.linspace(MP.NEAR, MP.FAR, MP.S, device=DEV)
@@ -97,9 +106,9 @@ def _train_fused(world, seed, steps, eval_steps):
     return curve
 
 
-def _train_dropin(world, seed, steps, eval_steps, autocast=True, losses=None, stop=None):
+def _train_dropin(world, seed, steps, eval_steps, autocast=True, losses=None, stop=None, ulps=0):
     g, mn, sig, batches, test = world
-    tables0, u, params0, ts = _setup(seed, steps)
+    tables0, u, params0, ts = _setup(seed, steps, ulps)
     enc, denc, mlp = _model(mn, sig, tables0, params0)
     nerf, vr, (oe, om, se, sm), crit = _dropin(world, enc, denc, mlp, steps)
     t_eval = torch.linspace(MP.NEAR, MP.FAR, MP.S, device=DEV)
@@ -151,30 +160,59 @@ def test_first_steps_follow_the_reference_loss_curve(world):
 
 
 @pytest.mark.parametrize("route", ["fused", "dropin"])
-def test_converged_psnr_is_not_below_the_reference(world, route):
+def test_converged_psnr_lies_inside_the_reference_envelope(world, route):
     g = world[0]
     steps, ev = int(g["steps"]), [int(v) for v in g["eval_steps"]]
     train = _train_fused if route == "fused" else _train_dropin
-    deltas, lines = [], []
-    for i, seed in enumerate(int(s) for s in g["seeds"]):
+    seeds = [int(s) for s in g["seeds"]]
+    ulps = [0] + [int(u) for u in g["self_ulps"]]
+    assert len(ulps) >= 4 and len(seeds) >= 5
+    ref = np.concatenate([g["psnr"][:, None, -1], g["psnr_self"][:, :, -1]], axis=1)   # [seed, perturbation], dB at the horizon
+    hip = np.zeros_like(ref)
+    for i, seed in enumerate(seeds):
         # the per-seed inputs regenerate to what the reference run used
         tables0, u, params0 = MP.seeded_inputs(seed, steps)
         assert abs(MP.checksum(tables0, u, *[v.numpy() for v in params0.values()]) - float(g["input_checksum"][i])) < 1e-6 * float(g["input_checksum"][i])
-        curve = np.array(train(world, seed, steps, set(ev)))
-        ref = g["psnr"][i]
-        tail = curve[int(len(curve) * 0.8):]
-        assert tail.max() - tail.min() < 0.2, f"seed {seed}: not on a plateau ({tail})"
-        deltas.append(curve[-1] - ref[-1])
-        lines.append(f"seed {seed}: reference {ref[-1]:.3f} dB (re-run with 1-ulp-moved tables {g['psnr_ulp'][i][-1]:.3f}), HIP {route} {curve[-1]:.3f} dB, "
-                     f"delta {deltas[-1]:+.3f}; at step {ev[len(ev) // 4]} delta {curve[len(ev) // 4] - ref[len(ev) // 4]:+.3f}")
-    deltas = np.array(deltas)
-    ulp = g["psnr_ulp"][:, -1] - g["psnr"][:, -1]
-    report = "\n".join(lines) + (f"\nHIP {route} - reference: mean {deltas.mean():+.3f} dB, sd {deltas.std():.3f}, max |delta| {np.abs(deltas).max():.3f}"
-                                 f"\nreference (1 ulp) - reference: mean {ulp.mean():+.3f} dB, sd {ulp.std():.3f}, max |delta| {np.abs(ulp).max():.3f}")
+        for j, up in enumerate(ulps):
+            curve = np.array(train(world, seed, steps, set(ev), ulps=up))
+            tail = curve[int(len(curve) * 0.8):]
+            assert tail.max() - tail.min() < 0.25, f"seed {seed} ulps {up:+d}: not on a plateau ({tail})"
+            hip[i, j] = curve[-1]
+    rm, hm = ref.mean(axis=1), hip.mean(axis=1)
+    sd_ref = float(np.sqrt(np.mean(np.var(ref, axis=1, ddof=1))))   # pooled within-seed sd: the reference against itself
+    sd_hip = float(np.sqrt(np.mean(np.var(hip, axis=1, ddof=1))))
+    d = hm - rm
+    D, se_seeds = float(d.mean()), float(d.std(ddof=1) / np.sqrt(len(d)))
+    z_noise = D / np.sqrt((sd_ref ** 2 + sd_hip ** 2) / hip.size)
+    self_delta = ref[:, 1:] - ref[:, :1]      # the reference's perturbed runs against its unperturbed ones
+    hip_delta = hip - ref[:, :1]              # the HIP runs against the same unperturbed reference runs
+    se_j = float(np.sqrt(self_delta.var(ddof=1) / self_delta.size + hip_delta.var(ddof=1) / hip_delta.size))
+    report = "\n".join(f"seed {s}: reference " + " ".join(f"{v:.2f}" for v in ref[i]) + f" (mean {rm[i]:.2f}) | HIP {route} " +
+                       " ".join(f"{v:.2f}" for v in hip[i]) + f" (mean {hm[i]:.2f}, delta {d[i]:+.2f})" for i, s in enumerate(seeds))
+    report += (f"\nperturbations (ulps of the initial tables): {ulps}"
+               f"\nHIP {route} - reference: D = {D:+.3f} dB, SE over the seeds {se_seeds:.3f}, z against within-seed noise alone {z_noise:+.2f}"
+               f"\nwithin-seed sd: reference {sd_ref:.3f} dB, HIP {sd_hip:.3f} dB ({sd_hip / sd_ref:.2f}x)"
+               f"\nmean delta against the unperturbed reference runs: HIP {hip_delta.mean():+.3f}; the reference's own {self_delta.mean():+.3f} +- {2 * se_j:.3f}")
     print(report)
-    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out")
-    if os.path.isdir(out):
-        with open(os.path.join(out, f"psnr_converged_{route}.txt"), "w") as f:
-            f.write(report + "\n")
-    assert deltas.mean() >= -0.3, report
-    assert np.abs(deltas).max() <= 3.0, report
+    assert abs(D) <= 2 * se_seeds, report                                              # (a) two-sided, paired over the seeds
+    assert abs(float(hip_delta.mean()) - float(self_delta.mean())) <= 2 * se_j, report   # (a) VERDICT r3's formulation
+    assert sd_hip <= 1.5 * sd_ref, report                                                # (b) no wider than the reference's own spread
+    assert np.abs(hip - rm[:, None]).max() <= 3.0, report                                # (c)
+
+
+def test_degenerate_initialisation_collapses_like_the_reference(world):
+    """Seed 5 (g15 `degenerate_seeds`): the reference's own modules never train from this initialisation - held-out PSNR
+    11.02 dB from step 50 to step 2000 (why round 3's seed list skipped it without saying so).  The HIP path, from the
+    same initialisation, must do the same thing: same plateau, to 0.2 dB, at a quarter of the horizon and at its end."""
+    g = world[0]
+    steps, ev = int(g["steps"]), [int(v) for v in g["eval_steps"]]
+    assert "degenerate_seeds" in g, "g15 holds no degenerate run"
+    for k, seed in enumerate(int(s) for s in g["degenerate_seeds"]):
+        tables0, u, params0 = MP.seeded_inputs(seed, steps)
+        assert abs(MP.checksum(tables0, u, *[v.numpy() for v in params0.values()]) - float(g["degenerate_input_checksum"][k])) < 1e-6 * float(g["degenerate_input_checksum"][k])
+        ref = g["psnr_degenerate"][k]
+        assert ref.max() < 12.0   # the fixture really is a run that never trained
+        curve = np.array(_train_fused(world, seed, steps, set(ev)))
+        q = len(ev) // 4
+        print(f"seed {seed}: reference {ref[q]:.3f} / {ref[-1]:.3f} dB at steps {ev[q]} / {ev[-1]}, HIP fused {curve[q]:.3f} / {curve[-1]:.3f} dB")
+        assert abs(curve[q] - ref[q]) < 0.2 and abs(curve[-1] - ref[-1]) < 0.2

@@ -44,6 +44,20 @@ def run(seed, cfg, ulps=0):
         prec = F32 if "fp32" in cfg else BF16
         tr = HashNeRFTrainer(enc, mlp, near=MP.NEAR, far=MP.FAR, num_samples=MP.S, total_steps=steps, precision=prec,
                              feat_dtype=F32 if "f32feat" in cfg else None, scatter_algo=1 if cfg.endswith("-algo1") else 0)
+        # "-rnoiseK": every gradient entry multiplied by (1 + K * 2^-24 * U(-1, 1)) in front of the optimiser - what K fp32
+        # roundings per accumulated sum would do (the HIP sums are exact integers / fixed-order fp32; the reference's CPU
+        # index_add and BLAS sums round at every step); "-anoiseK": K * 1e-10 * max|g| of additive Gaussian noise
+        import re as _re
+        m = _re.search(r"-(r|a)noise(\d+)", cfg)
+        if m:
+            kind, K = m.group(1), float(m.group(2))
+            gen = torch.Generator(device=DEV).manual_seed(1234 + seed)
+            def hook(g, kind=kind, K=K, gen=gen):
+                if kind == "r":
+                    g.mul_(1.0 + (torch.rand(g.shape, device=g.device, generator=gen) * 2 - 1) * (K * 2.0 ** -24))
+                else:
+                    g.add_(torch.randn(g.shape, device=g.device, generator=gen) * (K * 1e-10 * float(g.abs().max())))
+            tr.grad_hook = hook
         for k in range(steps):
             tr.step(*batches[k % MP.NB], t=ts[k])
             if k + 1 in ev:

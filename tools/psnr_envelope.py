@@ -1,0 +1,50 @@
+"""The reference's own run-to-run envelope (tests/golden/g15_converged_psnr.npz: per seed the unperturbed run + re-runs with
+the initial tables moved by +1 / -1 / +2 ulps) against HIP runs from the same inputs (JSON files written by
+tools/psnr_converged_study.py with PERTURBS=0,1,-1,2).  Prints the table DESIGN 4 / BASELINE.md quote.
+usage: python tools/psnr_envelope.py study1.json [study2.json ...]"""
+import json, os, sys
+import numpy as np
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+g = np.load(os.path.join(ROOT, "tests", "golden", "g15_converged_psnr.npz"))
+seeds = [int(s) for s in g["seeds"]]
+ulps = [0] + [int(u) for u in g["self_ulps"]]
+ref = np.concatenate([g["psnr"][:, None, -1], g["psnr_self"][:, :, -1]], axis=1)  # [seed, perturbation]
+
+
+def stats(x):  # x [seed, run]
+    within = np.sqrt(np.mean(np.var(x, axis=1, ddof=1)))
+    return x.mean(axis=1), within
+
+
+rm, rw = stats(ref)
+print("reference (its own modules, fp32 CPU), final held-out PSNR per seed over the perturbations", ulps)
+for i, s in enumerate(seeds):
+    print(f"  seed {s}: " + " ".join(f"{v:6.2f}" for v in ref[i]) + f"   mean {rm[i]:.2f}  range {ref[i].max() - ref[i].min():.2f}")
+self_delta = ref[:, 1:] - ref[:, :1]
+print(f"  pooled within-seed sd {rw:.3f} dB; self-deltas (perturbed - unperturbed, n = {self_delta.size}): mean {self_delta.mean():+.3f}  sd {self_delta.std(ddof=1):.3f}"
+      f"  min {self_delta.min():+.2f}  max {self_delta.max():+.2f}  SE {self_delta.std(ddof=1) / np.sqrt(self_delta.size):.3f}")
+if "degenerate_seeds" in g.files:
+    for s, p in zip(g["degenerate_seeds"], g["psnr_degenerate"]):
+        print(f"  seed {int(s)}: DEGENERATE - the reference itself stays at {p[-1]:.2f} dB for all 2000 steps (excluded)")
+cfgs = {}
+for f in sys.argv[1:]:
+    for cfg, v in json.load(open(f))["final_psnr_curves"].items():
+        cfgs.setdefault(cfg, {}).update(v)
+print("\nHIP - reference, per-seed means over the same perturbations (D = mean over seeds; SE_seeds = sd of the per-seed deltas / sqrt(n);")
+print("z_noise = D / sqrt((sd_ref^2 + sd_hip^2) / runs): the same difference against within-seed noise alone)")
+print(f"{'configuration':24s} " + " ".join(f"seed {s:<2d}" for s in seeds) + "      D     SE_seeds  z_noise  within-seed sd (ratio to ref)  vs self-delta interval")
+for cfg, v in cfgs.items():
+    try:
+        hip = np.array([[v[str(s)][str(u)][-1] for u in ulps] for s in seeds])
+    except KeyError:
+        continue
+    hm, hw = stats(hip)
+    d = hm - rm
+    D, se = d.mean(), d.std(ddof=1) / np.sqrt(len(d))
+    zn = D / np.sqrt((rw ** 2 + hw ** 2) / hip.size)
+    hd = hip - ref[:, :1]
+    se_j = np.sqrt(self_delta.var(ddof=1) / self_delta.size + hd.var(ddof=1) / hd.size)
+    print(f"{cfg:24s} " + " ".join(f"{x:+7.2f}" for x in d) + f"  {D:+6.2f}   {se:5.2f}    {zn:+5.1f}    {hw:.3f} ({hw / rw:.2f}x)"
+          f"                 mean delta vs unperturbed {hd.mean():+.2f}; self {self_delta.mean():+.2f} +- {2 * se_j:.2f}")
+    if "5" in v:
+        print(f"{'':24s} seed 5 (degenerate): HIP " + " ".join(f"{c[-1]:.2f}" for c in v["5"].values()) + " dB")
