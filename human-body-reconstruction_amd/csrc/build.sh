@@ -8,7 +8,7 @@ FLAGS=(--offload-arch=gfx950 -fvisibility=hidden -O3 -std=c++17 -fPIC -ffp-contr
 mkdir -p "$HERE/build"
 pids=()
 for f in c_api sample render hash_encode hash_scatter composite optim mlp; do
-  if [ ! -f "$HERE/build/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/build/$f.o" ] || [ "$HERE/hbr_common.h" -nt "$HERE/build/$f.o" ] || [ "$HERE/hash_common.h" -nt "$HERE/build/$f.o" ] || [ "$HERE/wave_reduce.h" -nt "$HERE/build/$f.o" ] || [ "$HERE/sample_common.h" -nt "$HERE/build/$f.o" ] || [ "$ROOT/include/hbr_hip.h" -nt "$HERE/build/$f.o" ]; then
+  if [ ! -f "$HERE/build/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/build/$f.o" ] || [ "$HERE/hbr_common.h" -nt "$HERE/build/$f.o" ] || [ "$HERE/hash_common.h" -nt "$HERE/build/$f.o" ] || [ "$HERE/wave_reduce.h" -nt "$HERE/build/$f.o" ] || [ "$HERE/sample_common.h" -nt "$HERE/build/$f.o" ] || [ "$HERE/composite_ray.h" -nt "$HERE/build/$f.o" ] || [ "$ROOT/include/hbr_hip.h" -nt "$HERE/build/$f.o" ]; then
     extra=()
     # mlp.hip: keep MFMA results in VGPRs (the VALU epilogues read every accumulator; the AGPR form costs ~650
     # v_accvgpr moves per 32-point tile in the backward kernel: 0.99 -> 0.93 ms)

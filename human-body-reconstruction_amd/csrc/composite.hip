@@ -3,6 +3,7 @@
 // lanes, the transmittance prefix is a wave-level scan (no LDS round trip for the scan itself).
 #include "hbr_common.h"
 #include "wave_reduce.h"
+#include "composite_ray.h"
 
 namespace hbr {
 
@@ -289,50 +290,25 @@ __global__ __launch_bounds__(kLossWaves * 64) void composite_loss_vec_kernel(Ray
     const float dn = in.dir_norm ? in.dir_norm[r] : 1.f;
     const float* tr = in.t + r * in.t_stride;
     const float4* row = (const float4*)in.rgb + r * S;
-    float4 v[NCH];
-    float Tr[NCH], ex[NCH], dl[NCH];
-    bool live[NCH];
+    RayComposite<NCH> rc;  // (composite_ray.h: shared with the fused render + backward kernel of mlp.hip)
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {  // all loads first
       const int s = c * 64 + lane;
-      v[c] = s < S ? row[s] : make_float4(0.f, 0.f, 0.f, 0.f);
-      dl[c] = s < S - 1 ? __fmul_rn(__fsub_rn(tr[s + 1], tr[s]), dn) : 0.f;  // helper.py:67,71; last delta stays 0
+      rc.v[c] = s < S ? row[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+      rc.dl[c] = s < S - 1 ? __fmul_rn(__fsub_rn(tr[s + 1], tr[s]), dn) : 0.f;  // helper.py:67,71; last delta stays 0
     }
-    float carry = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    rc.run(S, lane, gt[r * 3 + 0], gt[r * 3 + 1], gt[r * 3 + 2], k);
+    se += rc.se;
+    if (lane == 0 && Cr) {
+      Cr[r * 3 + 0] = rc.c0; Cr[r * 3 + 1] = rc.c1; Cr[r * 3 + 2] = rc.c2;
+    }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int s = c * 64 + lane;
-      float sg = v[c].w;
-      live[c] = s < S && !(sg < -10.f);  // helper.py:76
-      if (sg < -10.f) sg = -10.f;
-      const float p = s < S ? __fmul_rn(sg, dl[c]) : 0.f;
-      const WaveScan sc = wave_prefix_sum(p, lane);
-      Tr[c] = expf(-(carry + sc.excl));   // helper.py:93-95
-      ex[c] = expf(-p);
-      const float w = Tr[c] * (1.f - ex[c]);  // :91,:102
-      c0 += w * v[c].x; c1 += w * v[c].y; c2 += w * v[c].z;  // (padding lanes: v = 0)
-      carry += sc.total;
-    }
-    c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2);
-    const float e0 = c0 - gt[r * 3 + 0], e1 = c1 - gt[r * 3 + 1], e2 = c2 - gt[r * 3 + 2];
-    se += (e0 * e0 + e1 * e1) + e2 * e2;
-    const float g0 = k * e0, g1 = k * e1, g2 = k * e2;
-    if (lane == 0 && Cr) {
-      Cr[r * 3 + 0] = c0; Cr[r * 3 + 1] = c1; Cr[r * 3 + 2] = c2;
-    }
-    float suffix = 0.f;
-#pragma unroll
-    for (int c = NCH - 1; c >= 0; --c) {
-      const int s = c * 64 + lane;
-      const float w = Tr[c] * (1.f - ex[c]);
-      const float g = g0 * v[c].x + g1 * v[c].y + g2 * v[c].z;
-      const WaveScan rs = wave_suffix_sum(g * w, lane);
-      const float dp = g * Tr[c] * ex[c] - (suffix + rs.excl);
       if (s < S) {
         const bool kept = !keep || keep[r * S + s];
-        d_out[r * S + s] = kept ? make_float4(w * g0, w * g1, w * g2, live[c] ? dp * dl[c] : 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+        d_out[r * S + s] = kept ? rc.d[c] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      suffix += rs.total;
     }
   }
   closs_block_sum(se, ray_se, partials);

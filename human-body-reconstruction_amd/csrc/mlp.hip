@@ -24,6 +24,7 @@
 // fence, MFMAs pinned between epilogue words, vectors built whole) is there because of it - DESIGN.md section 3.
 #include "hbr_common.h"
 #include "sample_common.h"
+#include "composite_ray.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -515,7 +516,7 @@ __device__ __forceinline__ void load_tile_in(const FeatSrc& fs, const PeSrc& ps,
       ti.peA = *(const float4*)pr;
       ti.peB = *(const float4*)(pr + 32);
       ti.peC = *(const float4*)(pr + 64);
-      if (WITH_DOUT && h == 0) ti.dO = *(const float4*)((const char*)dout + n * 16u);
+      if (WITH_DOUT && dout && h == 0) ti.dO = *(const float4*)((const char*)dout + n * 16u);
     }
     return;
   }
@@ -540,7 +541,7 @@ __device__ __forceinline__ void load_tile_in(const FeatSrc& fs, const PeSrc& ps,
     ti.peA = *(const float4*)(pr + 4 * h);
     ti.peB = *(const float4*)(pr + 8 + 4 * h);
     ti.peC = *(const float4*)(pr + 16 + 4 * h);
-    if (WITH_DOUT && h == 0) ti.dO = ((const float4*)dout)[n];
+    if (WITH_DOUT && dout && h == 0) ti.dO = ((const float4*)dout)[n];
   }
 }
 
@@ -578,7 +579,7 @@ __device__ __forceinline__ void load_tile_part(const FeatSrc& fs, const PeSrc& p
     if (valid) {
       const char* pr = (const char*)ps.pe + (c.ray * 96u + 16u * (uint32_t)h);
       ti.peC = *(const float4*)(pr + 64);
-      if (h == 0) ti.dO = *(const float4*)((const char*)dout + c.n * 16u);
+      if (dout && h == 0) ti.dO = *(const float4*)((const char*)dout + c.n * 16u);  // (dout == nullptr: the render variant forms d out itself)
     }
   }
 }
@@ -1252,14 +1253,34 @@ __device__ __forceinline__ void dense_mask_take(const char* img, int fbase, int 
   }
 }
 
-template <class P, int LAYOUT, int DT, bool WLDS>
+// RENDER (round 4; hbr_mlp_render_bwd): the training step's K3 + K5 + K4 in ONE kernel.  The backward recomputes the forward of
+// its tile anyway, and with S in {32, 64, 128} samples per ray the four waves of a workgroup hold 4 x 32 consecutive
+// points = whole rays - so the raw (rgb, sigma) the recompute ends in are activated (test_hash.py:62,67), parked in
+// LDS (2 KiB), and after ONE barrier every wave composites ITS ray from them (composite_ray.h: the operations of
+// composite_loss_vec_kernel in its order, the same bits on the same inputs), forms dL/dC = k (C - gt) and the gradient
+// of its own 32 samples, which is the `d out` the rest of the kernel reads from memory otherwise.  The forward launch
+// (0.065 ms), the compositing launches (0.020 ms) and 2 x 33 MB of [N,4] traffic are gone; the wave that holds a ray's
+// first samples adds its squared error to a per-wave partial (fixed order; summed by mlp_dw_finalize_kernel).
+struct RenderArgs {
+  const float* t;         // [S] shared depths
+  const float* dir_norm;  // [R] or nullptr (= 1)
+  const float* gt;        // [R,3]
+  float k;                // gscale * 4 / (3 R)
+  float* se_part;         // [gridDim.x * 4] per-wave sums of (C - gt)^2, written
+  float* Cr;              // optional [R,3] out
+  uint32_t S;
+};
+constexpr int kRenderLdsBytes = 4 * 32 * 16;  // (r, g, b, sigma) of the workgroup's 128 points
+
+template <class P, int LAYOUT, int DT, bool WLDS, bool RENDER = false>
 __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restrict__ gimg, FeatSrc fs, PeSrc ps,
                                                             const float* __restrict__ dout, DFeatDst dfd,
-                                                            float* __restrict__ slabs) {
+                                                            float* __restrict__ slabs, RenderArgs ra) {
   using T = Tab<P>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* xch = smem;
   char* limg = smem + Xch<P>::BYTES;
+  float4* rays = (float4*)(smem + Xch<P>::BYTES + (WLDS ? (T::IMG_BYTES + 15) / 16 * 16 : 0));  // RENDER only
   if (WLDS) stage_image(limg, gimg, T::IMG_BYTES);
   // the exchange image is read in whole 32-feature tiles even where a layer writes fewer: start from zeros, not from
   // whatever bit patterns the LDS held
@@ -1291,6 +1312,18 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
   ba.init(lane);
   int buf = 0;
 
+  // RENDER: a lane's samples of ITS ray are always 64 c + lane: the depth differences are loop constants
+  float tdl[2] = {0.f, 0.f};
+  float se_acc = 0.f;
+  const int wpr = RENDER ? (int)(ra.S >> 5) : 1;   // waves per ray: 1, 2 or 4
+  const int wr = wv & (wpr - 1);                    // this wave's position in its ray
+  if constexpr (RENDER) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const uint32_t sidx = 64u * c + (uint32_t)lane;
+      if (sidx + 1u < ra.S) tdl[c] = __fsub_rn(ra.t[sidx + 1u], ra.t[sidx]);
+    }
+  }
   TileIn nxt;
   TileCursor ahead;  // the tile being prefetched
   ahead.start((blockIdx.x * 4 + wv) * 32 + (lane & 31), stride * 32, ps.group);
@@ -1319,7 +1352,38 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
     if constexpr (P::ELEMS == 8) forward_tile_prefetched<DT>(img, cur, lane, sv, pc);
     else forward_tile<P, DT, true>(img, bias, cur, lane, sv, pc);
     const int lofs = opaque_lane_offset<P>(lane);
-    const float4 dO = cur.dO;  // zero on invalid lanes => every dZ of such a point is zero
+    float4 dO = cur.dO;  // zero on invalid lanes => every dZ of such a point is zero
+    if constexpr (RENDER) {
+      // my 32 points' activated outputs -> LDS (what hbr_mlp_fwd writes to out[N,4]: elu(rgb) + 1, leaky sigma)
+      if (h == 0) rays[wv * 32 + lane] = valid ? make_float4(elu1(sv.raw[0]), elu1(sv.raw[1]), elu1(sv.raw[2]), lrelu(sv.s0)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      __syncthreads();  // (the next round's writes come after this round's six exchange barriers: one buffer suffices)
+      const uint32_t ray = (tile - (uint32_t)wr) / (uint32_t)wpr;  // tiles of a ray are consecutive and aligned: N = R * S
+      const bool rvalid = tile < ntiles;                            // uniform: a ray is in the launch whole or not at all
+      dO = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rvalid) {
+        const float dn = ra.dir_norm ? ra.dir_norm[ray] : 1.f;
+        const float4* row = rays + (wv - wr) * 32;  // the ray's S samples
+        RayComposite<2> rc;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const uint32_t sidx = 64u * c + (uint32_t)lane;
+          rc.v[c] = sidx < ra.S ? row[sidx] : make_float4(0.f, 0.f, 0.f, 0.f);
+          rc.dl[c] = __fmul_rn(tdl[c], dn);  // helper.py:67,71 (0 for the last sample and beyond)
+        }
+        rc.run((int)ra.S, lane, ra.gt[ray * 3 + 0], ra.gt[ray * 3 + 1], ra.gt[ray * 3 + 2], ra.k);
+        if (wr == 0) {
+          se_acc += rc.se;
+          if (ra.Cr && lane == 0) { ra.Cr[ray * 3 + 0] = rc.c0; ra.Cr[ray * 3 + 1] = rc.c1; ra.Cr[ray * 3 + 2] = rc.c2; }
+        }
+        // my samples are 32 wr + (lane & 31): chunk wr >> 1, lanes 32 (wr & 1) + ...
+        float4 mine = (wr & 2) ? rc.d[1] : rc.d[0];
+        if (wr & 1) {
+          const int src = (lane & 31) + 32;
+          mine = make_float4(__shfl(mine.x, src), __shfl(mine.y, src), __shfl(mine.z, src), __shfl(mine.w, src));
+        }
+        if (h == 0 && valid) dO = mine;
+      }
+    }
 
     // ---- C3
     typename P::frag dz3[P::S8];
@@ -1437,6 +1501,9 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
     };
     park(L1, Own<1, 2>(wv).m, 2); park(L2, Own<2, 2>(wv).m, 2); park(L3, Own<2, 1>(wv).m, 1);
     park(C1, Own<2, 2>(wv).m, 2); park(C2, Own<2, 2>(wv).m, 2); park(C3, Own<2, 1>(wv).m, 1);
+  }
+  if constexpr (RENDER) {
+    if (lane == 0) ra.se_part[blockIdx.x * 4 + wv] = se_acc;
   }
   float* mine = slabs + ((size_t)blockIdx.x * 4 + wv) * kSlabWave + lane;
 #pragma unroll
