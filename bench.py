@@ -366,7 +366,8 @@ def main():
         if kern:
             roofs["hash_fwd"] = dict(bound="hbm", achieved=hash_fwd_bytes(fb) * N / (kern["hash_fwd"] * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
             roofs["hash_bwd"] = dict(bound="hbm", achieved=hash_bwd_bytes(fb) * N / (kern["hash_bwd"] * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
-            roofs["mlp_fwd"] = dict(bound="mfma", achieved=MLP_FWD_FLOP * N / (kern["mlp_fwd"] * 1e-3) / 1e12, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s")
+            if "mlp_fwd" in kern:  # (absent when the step runs hbr_mlp_render_bwd: the forward is part of the backward launch)
+                roofs["mlp_fwd"] = dict(bound="mfma", achieved=MLP_FWD_FLOP * N / (kern["mlp_fwd"] * 1e-3) / 1e12, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s")
             roofs["mlp_bwd"] = dict(bound="mfma", achieved=MLP_BWD_FLOP * N / (kern["mlp_bwd"] * 1e-3) / 1e12, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s")
             # Stored profile numbers (rocprofv3 --pmc passes cannot run inside this process): HBM bytes per launch and the
             # issue-side counters, each labelled with the profile it came from so that a stale file cannot pass as live.
@@ -451,6 +452,8 @@ def main():
                            "rays_per_rank": R, "samples_per_ray": S, "global_rays": R * world, "levels": 16, "table_rows": T,
                            "parallelism": f"ray-sharded dp{world}, 1 all-reduce/step" if world > 1 else "single GPU"},
                 "loss": loss,
+                # the step's MLP forward + compositing + loss + backward as ONE launch (hbr_mlp_render_bwd; then no mlp_fwd entry in `kernels`)
+                "fused_render": bool(tr.timers is not None and "mlp_fwd" not in tr.timers) if not args.no_kernel_events else None,
                 "roofline": roofs.get(dominant), "roofline_hash_lookup": roofs.get("hash_fwd"), "kernels": roofs or None,
                 "cpu_baseline": cpu,
                 # multi-GPU diagnostics: the one all-reduce per step of the flat 8.05 MiB gradient buffer

@@ -36,6 +36,7 @@ SIGNATURES = {
     "hbr_mlp_workspace_bytes": (_l, [_i]),
     "hbr_mlp_fwd": (_i, [_p, _i, _l, _i, _p, _l, _l, _p, _i, _p, _p, _p, _l, _p]),
     "hbr_mlp_bwd": (_i, [_p, _i, _l, _i, _p, _l, _l, _p, _i, _p, _p, _p, _p, _p, _l, _p]),
+    "hbr_mlp_render_bwd": (_i, [_p, _i, _l, _i, _p, _l, _l, _p, _i, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _l, _p]),
     "hbr_render_fwd_workspace_bytes": (_l, [_l, _l, _i, _i, _i, _i]),
     "hbr_render_fwd": (_i, [_p, _p, _p, _p, _l, _l, _p, _p, _p, _f, _i, _l, _i, _p, _i, _i, _p, _p, _p, _p, _p, _l, _p]),
     "hbr_mse2_workspace_bytes": (_l, []),

@@ -944,7 +944,18 @@ __global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(const float* __restr
 // a tile of a two-tile layer, and the 4 waves x 2 lane halves that hold partial sums of one bias row - so ONE of them
 // (the "leader": the even wave / wave 0's lower half) adds up its siblings in a fixed order and the others return:
 // every parameter has exactly one writer and one summation order, i.e. the MLP gradient is bitwise reproducible.
-__global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(const float* __restrict__ tot, float* __restrict__ dparams, bool swapped, bool overwrite) {
+// (hbr_mlp_render_bwd: one more block adds up the waves' squared-error partials, lane-strided then by DPP - a fixed order -
+// and WRITES loss = se_scale * sum.)
+__global__ __launch_bounds__(256) void mlp_dw_finalize_kernel(const float* __restrict__ tot, float* __restrict__ dparams, bool swapped, bool overwrite,
+                                                              const float* __restrict__ se_part, int n_se, float se_scale, float* __restrict__ loss_out) {
+  if (blockIdx.x == (kSlabWg + 255) / 256) {  // the extra block of a render launch
+    if (threadIdx.x >= 64) return;
+    float sum = 0.f;
+    for (int i = threadIdx.x; i < n_se; i += 64) sum += se_part[i];
+    sum = wave_reduce(sum, [](float a, float b) { return a + b; });
+    if (threadIdx.x == 0) *loss_out = se_scale * sum;
+    return;
+  }
   const int e = blockIdx.x * 256 + threadIdx.x;  // (wave, register, lane) of the slab layout
   if (e >= kSlabWg) return;
   const int lane = e & 63, r = (e >> 6) % kSlabRegs, wv = e / kSlabWave, h = lane >> 5;
@@ -1593,22 +1604,38 @@ static int launch_fwd(int dt, uint32_t blocks, hipStream_t st, const char* img, 
   return launch_with_lds(mlp_fwd_kernel<P, LAYOUT, HBR_BF16>, dim3(blocks), dim3(kFwdWaves * 64), lds, st, img, fs, ps, out, keep);
 }
 
+// render != nullptr (bf16, planar): the RENDER instantiation - d out is formed in the kernel, *loss_out is written
 template <class P, int LAYOUT, int DT, bool WLDS>
 static int launch_bwd_fused(uint32_t ntiles, hipStream_t st, const char* img, FeatSrc fs, PeSrc ps, const float* dout,
-                            DFeatDst dfd, float* dparams, float* absmax_out, bool overwrite) {
+                            DFeatDst dfd, float* dparams, float* absmax_out, bool overwrite, const RenderArgs* render = nullptr,
+                            float se_scale = 0.f, float* loss_out = nullptr) {
   using T = Tab<P>;
-  const int lds = Xch<P>::BYTES + (WLDS ? T::IMG_BYTES : 0);
+  const int lds = Xch<P>::BYTES + (WLDS ? (T::IMG_BYTES + 15) / 16 * 16 : 0) + (render ? kRenderLdsBytes : 0);
   uint32_t blocks = (ntiles + 3) / 4;
   if (blocks > kMaxBwdBlocks) blocks = kMaxBwdBlocks;  // one workgroup per CU; each sweeps its share of the tiles in rounds of four
   float* slabs = (float*)(const_cast<char*>(img) + slab_offset_bytes(T::IMG_BYTES));  // behind the fragment image in `ws`
   const bool want_abs = absmax_out && dfd.p;
   dfd.abs_part = want_abs ? (uint32_t*)(slabs + (size_t)kMaxBwdBlocks * kSlabWg) : nullptr;  // behind the slabs
-  int rc = launch_with_lds(mlp_bwd_fused_kernel<P, LAYOUT, DT, WLDS>, dim3(blocks), dim3(256), lds, st, img, fs, ps, dout, dfd, slabs);
-  if (rc) return rc;
   float* tot = slabs + (size_t)kMaxBwdBlocks * kSlabWg + 16 * (size_t)kAbsWaves;  // behind the maxima
+  float* se_part = tot + kSlabWg;                                                   // behind the totals: one float per wave
+  int rc;
+  if constexpr (std::is_same<P, PBf16>::value && LAYOUT == HBR_LAYOUT_PLANAR && WLDS) {
+    if (render) {
+      RenderArgs ra = *render;
+      ra.se_part = se_part;
+      rc = launch_with_lds(mlp_bwd_fused_kernel<P, LAYOUT, DT, WLDS, true>, dim3(blocks), dim3(256), lds, st, img, fs, ps, dout, dfd, slabs, ra);
+    } else {
+      rc = launch_with_lds(mlp_bwd_fused_kernel<P, LAYOUT, DT, WLDS, false>, dim3(blocks), dim3(256), lds, st, img, fs, ps, dout, dfd, slabs, RenderArgs{});
+    }
+  } else {
+    if (render) return HBR_EUNSUPPORTED;
+    rc = launch_with_lds(mlp_bwd_fused_kernel<P, LAYOUT, DT, WLDS, false>, dim3(blocks), dim3(256), lds, st, img, fs, ps, dout, dfd, slabs, RenderArgs{});
+  }
+  if (rc) return rc;
   hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(kSlabWg / 32 + (want_abs ? 16 : 0)), dim3(256), 0, st, (const float*)slabs, (int)blocks,
                      tot, (const uint32_t*)dfd.abs_part, absmax_out, kXchSwapped<P>);
-  hipLaunchKernelGGL(mlp_dw_finalize_kernel, dim3((kSlabWg + 255) / 256), dim3(256), 0, st, (const float*)tot, dparams, kXchSwapped<P>, overwrite);
+  hipLaunchKernelGGL(mlp_dw_finalize_kernel, dim3((kSlabWg + 255) / 256 + (render ? 1 : 0)), dim3(256), 0, st, (const float*)tot, dparams,
+                     kXchSwapped<P>, overwrite, (const float*)se_part, (int)blocks * 4, se_scale, loss_out);
   return HBR_OK;
 }
 
@@ -1660,7 +1687,8 @@ extern "C" int hbr_debug_k4_prof(unsigned long long* out64, int reset) {  // dev
 extern "C" int64_t hbr_mlp_workspace_bytes(int precision) {
   // the MFMA-fragment image of the weights, then (backward only) one weight-gradient slab per workgroup
   const int64_t img = precision == HBR_BF16 ? Tab<PBf16>::IMG_BYTES : Tab<PF32>::IMG_BYTES;
-  return slab_offset_bytes(img) + ((int64_t)kMaxBwdBlocks * kSlabWg + 16 * (int64_t)kAbsWaves + kSlabWg) * (int64_t)sizeof(float);
+  // ... the per-wave feature-gradient maxima, one slab of totals, and (hbr_mlp_render_bwd) one squared-error partial per wave
+  return slab_offset_bytes(img) + ((int64_t)kMaxBwdBlocks * kSlabWg + 16 * (int64_t)kAbsWaves + kSlabWg + (int64_t)kMaxBwdBlocks * 4) * (int64_t)sizeof(float);
 }
 
 extern "C" int hbr_dir_encode(const float* x, int64_t rows, int d_model, int num_freq, float* out, void* stream) {
@@ -1760,6 +1788,39 @@ extern "C" int hbr_mlp_bwd(const void* feat, int layout, int64_t feat_stride, in
     if (feat_dtype == HBR_F32) rc = launch_bwd<HBR_LAYOUT_ROWS, HBR_F32>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams, dfeat_absmax, overwrite);
     else rc = launch_bwd<HBR_LAYOUT_ROWS, HBR_BF16>(precision, ntiles, st, img, fs, ps, dout, dfd, dparams, dfeat_absmax, overwrite);
   }
+  if (rc) return rc;
+  HBR_RETURN_IF_LAUNCH_FAILED();
+  return HBR_OK;
+}
+
+// K3 + K5 + K4 of a training step in one call (mlp_bwd_fused_kernel<..., RENDER>): see include/hbr_hip.h
+extern "C" int hbr_mlp_render_bwd(const void* feat, int layout, int64_t feat_stride, int feat_dtype, const float* viewdirs_enc,
+                                  int64_t R, int64_t S, const float* params, int precision, const float* t, const float* dir_norm,
+                                  const float* gt, float gscale, float* loss_out, float* Cr, void* dfeat, float* dfeat_absmax,
+                                  float* dparams, void* ws, int64_t ws_bytes, void* stream) {
+  const bool image_ready = (precision & HBR_IMAGE_READY) != 0;
+  const bool overwrite = (precision & HBR_OVERWRITE) != 0;
+  precision &= ~(HBR_IMAGE_READY | HBR_OVERWRITE);
+  if (R < 0 || S < 1) return HBR_EINVAL;
+  const int64_t N = R * S;
+  int rc = check_common(feat, layout, feat_stride, feat_dtype, viewdirs_enc, N, S, params, precision, ws, ws_bytes);
+  if (rc) return rc;
+  if (!t || !gt || !loss_out || !dparams) return HBR_EINVAL;
+  // whole rays per workgroup round (4 waves x 32 points), bf16 MFMA, planar features: anything else takes the three separate calls
+  if (precision != HBR_BF16 || layout != HBR_LAYOUT_PLANAR || (S != 32 && S != 64 && S != 128) || R < 1) return HBR_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  FeatSrc fs{feat, feat_stride, (uint32_t)N, addr32_ok(N, S)};
+  PeSrc ps{viewdirs_enc, (uint32_t)S};
+  DFeatDst dfd{dfeat, feat_stride, nullptr};
+  const uint32_t ntiles = (uint32_t)(N / 32);
+  char* img = (char*)ws;
+  if (!image_ready) pack<PBf16>(params, img, st);
+  RenderArgs ra{t, dir_norm, gt, gscale * 4.f * (1.0f / (float)(R * 3)), nullptr, Cr, (uint32_t)S};
+  const float se_scale = 2.f * (1.0f / (float)(R * 3));
+  if (feat_dtype == HBR_F32)
+    rc = launch_bwd_fused<PBf16, HBR_LAYOUT_PLANAR, HBR_F32, true>(ntiles, st, img, fs, ps, nullptr, dfd, dparams, dfeat_absmax, overwrite, &ra, se_scale, loss_out);
+  else
+    rc = launch_bwd_fused<PBf16, HBR_LAYOUT_PLANAR, HBR_BF16, true>(ntiles, st, img, fs, ps, nullptr, dfd, dparams, dfeat_absmax, overwrite, &ra, se_scale, loss_out);
   if (rc) return rc;
   HBR_RETURN_IF_LAUNCH_FAILED();
   return HBR_OK;

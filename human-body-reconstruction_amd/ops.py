@@ -328,6 +328,42 @@ def mlp_bwd(feat: torch.Tensor, layout: int, viewdirs_enc: torch.Tensor, group: 
     return dfeat
 
 
+def mlp_render_bwd(feat: torch.Tensor, viewdirs_enc: torch.Tensor, params: torch.Tensor, precision: int, t: torch.Tensor,
+                   dir_norm: Optional[torch.Tensor], gt: torch.Tensor, dparams: torch.Tensor, gscale: float = 1.0,
+                   absmax_out: Optional[torch.Tensor] = None, image_ready: Optional[bool] = False, overwrite: bool = False,
+                   want_Cr: bool = False):
+    """mlp_fwd + composite_loss_fwd_bwd + mlp_bwd of a training step in ONE launch (hbr_mlp_render_bwd): planar
+    features [16, R*S, 2], shared depths t[S], S in {32, 64, 128}, bf16 MLP.  Returns (loss 0-d, dfeat, Cr or None), or
+    None when the library refuses the shape (the caller then issues the three separate calls)."""
+    require_gpu(feat)
+    N, stride, dtype = _feat_desc(feat, PLANAR)
+    S = int(t.shape[0])
+    if precision != BF16 or t.dim() != 1 or S not in (32, 64, 128) or N % S or N == 0:
+        return None
+    R = N // S
+    gt, t = _f32c(gt), _f32c(t)
+    if dir_norm is not None:
+        dir_norm = _f32c(dir_norm).reshape(-1)
+        if dir_norm.numel() != R:
+            raise HbrError("dir_norm must hold one value per ray")
+    dfeat = torch.empty_like(feat)
+    loss = torch.empty((), dtype=torch.float32, device=feat.device)
+    Cr = torch.empty((R, 3), dtype=torch.float32, device=feat.device) if want_Cr else None
+    ws = _mlp_ws(precision, feat.device)
+    ikey = (feat.device, _stream(), precision)
+    if image_ready is None:
+        image_ready = _mlp_image.get(ikey) == (ws.data_ptr(), _image_key(params))
+    rc = lib().hbr_mlp_render_bwd(feat.data_ptr(), PLANAR, stride, dtype, viewdirs_enc.data_ptr(), R, S, params.data_ptr(),
+                                  precision | (IMAGE_READY if image_ready else 0) | (OVERWRITE if overwrite else 0), t.data_ptr(),
+                                  _ptr(dir_norm), gt.data_ptr(), float(gscale), loss.data_ptr(), _ptr(Cr), dfeat.data_ptr(),
+                                  _ptr(absmax_out), dparams.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    if rc == EUNSUPPORTED:
+        return None
+    check(rc, "hbr_mlp_render_bwd")
+    _mlp_image[ikey] = (ws.data_ptr(), _image_key(params))
+    return loss, dfeat, Cr
+
+
 def _t_stride(t, S):
     """0 for the shared t[S]; S for a contiguous per-ray t[R,S]."""
     return 0 if t.dim() == 1 else S

@@ -90,6 +90,8 @@ class HashNeRFTrainer:
         # loss + compositing backward, one Adam launch.  HBR_FUSED_SMALL=0: the separate launches (A/B, tests).
         import os
         self.fused_small = os.environ.get("HBR_FUSED_SMALL", "1") != "0"
+        # MLP forward + compositing + loss + backward as one launch where the shape allows (HBR_FUSED_RENDER=0: the separate launches)
+        self.fused_render = os.environ.get("HBR_FUSED_RENDER", "1") != "0"
 
     # ---- helpers ------------------------------------------------------------------------------
     def _bind_parameters(self):
@@ -173,6 +175,18 @@ class HashNeRFTrainer:
         rays = (rays_o, rays_d, t)
         # forward
         feat = self._timed("hash_fwd", lambda: ops.hash_encode_fwd(g, self.tables, rays=rays, layout=PLANAR, dtype=self.feat_dtype))
+        amax = self._amax  # (L == 16: checked in __init__)
+        # Round 4: MLP forward + compositing + loss + their backward in ONE launch (hbr_mlp_render_bwd) where whole rays fit a
+        # workgroup round of the backward kernel - S in {32, 64, 128}, bf16 MLP, per-ray dir_norm tensor or none.
+        rendered = None
+        if fused and self.fused_render and self.precision == BF16:
+            rendered = self._timed("mlp_bwd", lambda: ops.mlp_render_bwd(feat, pe, self.flat, self.precision, t, dn, gt, self.g_mlp, absmax_out=amax,
+                                                                         image_ready=True, overwrite=True))
+            if rendered is None and self.timers is not None:
+                self.timers["mlp_bwd"].pop()  # the library refused the shape: the span timed nothing
+        if rendered is not None:
+            loss, dfeat, _ = rendered
+            return self._finish_step(loss, dfeat, rays, amax, g, R, S)
         out = self._timed("mlp_fwd", lambda: ops.mlp_fwd(feat, PLANAR, pe, S, self.flat, self.precision, image_ready=fused))
         if fused:
             # ONE launch: compositing, loss = 2*MSE and its gradient, compositing backward (each ray in its own wave)
@@ -185,10 +199,13 @@ class HashNeRFTrainer:
         # No memset of the 8 MiB gradient buffer: K4 and K2 WRITE their outputs (`overwrite`; where K2 runs a path that
         # can only accumulate, ops zeroes that slice itself).  The padding behind the MLP block is never written.
         # K4 also reports max |d feat| per level: K2's fixed-point scale, without K2 re-reading the buffer for it
-        amax = self._amax  # (L == 16: checked in __init__)
         # (image_ready: the workspace still holds the weight fragments this step's mlp_fwd packed from self.flat)
         dfeat = self._timed("mlp_bwd", lambda: ops.mlp_bwd(feat, PLANAR, pe, S, self.flat, self.precision, d_out, self.g_mlp,
                                                            absmax_out=amax, image_ready=True, overwrite=True))
+        return self._finish_step(loss, dfeat, rays, amax, g, R, S)
+
+    def _finish_step(self, loss, dfeat, rays, amax, g, R, S):
+        """K2, the step's one all-reduce, the optimiser."""
         if self.split_scatter and g.L >= 2:
             # The step's one all-reduce, issued in two pieces that partition the flat gradient buffer: the upper levels
             # together with the MLP block (final after K4) while the lower levels' scatter is still running, then the

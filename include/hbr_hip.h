@@ -242,6 +242,26 @@ HBR_API int hbr_mlp_bwd(const void* feat, int layout, int64_t feat_stride, int f
                 int precision, const float* dout, void* dfeat, float* dfeat_absmax, float* dparams,
                 void* ws, int64_t ws_bytes, void* stream);
 
+/* ---- the MLP + compositing + loss of a training step, forward AND backward, in one call (round 4) -----------------
+ * hbr_mlp_fwd + hbr_composite_loss_fwd_bwd + hbr_mlp_bwd fused: replaces MLP_3D.forward (test_hash.py:52-72), calc_color
+ * (helper.py:53-107), loss = MSE(Cr, gt) + MSE(Cf, gt) with Cf = Cr (train_hash2.py:221) and their autograd.  The backward
+ * kernel recomputes the forward of its 32-point tile anyway; with whole rays inside a workgroup round (S in {32, 64, 128},
+ * shared depths t[S]) it composites them in LDS and forms d out itself - the forward launch, the compositing launches and
+ * the [N,4] out / d out buffers disappear.  Same arithmetic as the three calls (compositing: the same operations in the
+ * same order; the MLP forward is the backward kernel's recompute, i.e. the bias enters by an extra MFMA k-step: colours
+ * agree to ~1e-6 relative).
+ *   feat, layout, feat_stride, feat_dtype, viewdirs_enc [R,24], params, dfeat, dfeat_absmax, dparams, ws: as hbr_mlp_bwd
+ *            (N = R * S points, ray-major; group = S); precision: HBR_BF16 (| HBR_IMAGE_READY | HBR_OVERWRITE)
+ *   t [S], dir_norm [R] or NULL, gt [R,3], gscale: as hbr_composite_loss_fwd_bwd
+ *   loss_out one fp32, WRITTEN (fixed summation order: bitwise reproducible);  Cr [R,3] out or NULL
+ *   returns HBR_EUNSUPPORTED - before launching anything - for fp32 precision, the rows layout or another S: the caller
+ *   then issues the three separate calls.
+ */
+HBR_API int hbr_mlp_render_bwd(const void* feat, int layout, int64_t feat_stride, int feat_dtype, const float* viewdirs_enc,
+                       int64_t R, int64_t S, const float* params, int precision, const float* t, const float* dir_norm,
+                       const float* gt, float gscale, float* loss_out, float* Cr, void* dfeat, float* dfeat_absmax,
+                       float* dparams, void* ws, int64_t ws_bytes, void* stream);
+
 /* ---- vol_render, inference half, in one call ----------------------------------------------------
  * Replaces vol_renderer.py:141-223 under no_grad (the image-write loop, train_hash2.py:277-292; hierarchical off):
  * direction encoding -> K1 (points o + d*t generated on chip, planar features in `feat_dtype`) -> K3 -> K5, enqueued

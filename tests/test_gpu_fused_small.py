@@ -155,6 +155,7 @@ def test_trainer_folded_launches_equal_separate_launches():
                 lvl.weight.mul_(3000.0)  # features of order 0.3: a field whose gradients are not all ~0
         tr = HashNeRFTrainer(enc, mlp, num_samples=64, total_steps=100, precision=BF16, seed=3)
         tr.fused_small = fused
+        tr.fused_render = False  # (round 4's one-launch MLP + compositing has its own comparison: tests/test_gpu_render_bwd.py)
         p0 = tr.tables.clone()
         loss = float(tr.step(o, d, dn, gt))
         states.append((tr.grad.clone(), tr.tables.clone() - p0, tr.flat.clone(), loss))

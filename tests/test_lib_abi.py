@@ -40,7 +40,8 @@ def test_header_symbols_all_exported(L):
     img = (34 + 10 + 28) * 1024 + 6 * 64 * 4  # 10: one bias k-step per forward output tile
     assert img % 256 == 0
     # ... the per-wave feature-gradient maxima of the backward (16 levels x 1024 waves x 4 B) and one slab of totals
-    slabs = 256 * 4 * (6 * 16 + 10) * 64 * 4 + 16 * 1024 * 4 + 4 * (6 * 16 + 10) * 64 * 4
+    # ... and (hbr_mlp_render_bwd) one squared-error partial per wave of the backward grid
+    slabs = 256 * 4 * (6 * 16 + 10) * 64 * 4 + 16 * 1024 * 4 + 4 * (6 * 16 + 10) * 64 * 4 + 256 * 4 * 4
     assert lib.hbr_mlp_workspace_bytes(L.BF16) == img + slabs
     img32 = (264 + 216) * 256 + 6 * 64 * 4
     assert lib.hbr_mlp_workspace_bytes(L.F32) == (img32 + 255) // 256 * 256 + slabs
