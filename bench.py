@@ -385,7 +385,9 @@ def main():
             # HBM bytes a launch cannot avoid at this size: K1 tables once + the feature write; K2 the feature-gradient read,
             # the gradient-table write and the normalised coordinates (written once); K3/K4 their streams
             compulsory = {"hash_fwd": 16 * T * 8 + N * 32 * fb, "hash_bwd": N * 32 * fb + 16 * T * 8 + N * 12,
-                          "mlp_fwd": N * 32 * fb + N * 16, "mlp_bwd": 2 * N * 32 * fb + 2 * N * 16}
+                          "mlp_fwd": N * 32 * fb + N * 16,
+                          # (the one-launch render + backward reads the features and writes their gradient; no [N,4] out / d out)
+                          "mlp_bwd": 2 * N * 32 * fb + (2 * N * 16 if "mlp_fwd" in kern else 0)}
             for k, r in roofs.items():
                 r["frac"] = r["achieved"] / r["peak"]
                 r["kernel"] = k

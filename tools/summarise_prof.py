@@ -139,10 +139,12 @@ for r in blocks:
         k = r["kernel"]
         r["traffic"] = traffic[k]
         r["traffic_source"] = traffic["source"] + " (stored rocprofv3 --pmc profile of this configuration, not measured in this run)"
+        r["traffic_source_stale"] = False  # these counters were taken on the very build this line was measured on
         if r.get("bound") == "hbm":
             r["hbm_frac"] = traffic[k] / (r["avg_ms"] * 1e-3) / 1e9 / 8000.0
         if k in issue:
             r["roofline_issue"] = issue[k]
+            r["roofline_issue_stale"] = False
 open(os.path.join(dst, f"{tag}_bench.json"), "w").write(json.dumps(rec) + "\n")
 print(open(os.path.join(dst, f"{tag}_pmc_hbm.csv")).read())
 print(json.dumps(issue, indent=1))
