@@ -369,6 +369,11 @@ def main():
             if "mlp_fwd" in kern:  # (absent when the step runs hbr_mlp_render_bwd: the forward is part of the backward launch)
                 roofs["mlp_fwd"] = dict(bound="mfma", achieved=MLP_FWD_FLOP * N / (kern["mlp_fwd"] * 1e-3) / 1e12, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s")
             roofs["mlp_bwd"] = dict(bound="mfma", achieved=MLP_BWD_FLOP * N / (kern["mlp_bwd"] * 1e-3) / 1e12, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s")
+            if "mlp_fwd" not in kern:
+                # hbr_mlp_render_bwd: ONE launch does the MLP forward (once - no separate forward, no recompute), the compositing,
+                # the loss and the MLP backward: the same 3 x 27 904 FLOP per sample are now ALL the MLP arithmetic of the step
+                roofs["mlp_bwd"]["covers"] = ("MLP forward + alpha compositing + loss + MLP backward in one launch (hbr_mlp_render_bwd); "
+                                             "the step has no separate mlp_fwd / compositing launches")
             # Stored profile numbers (rocprofv3 --pmc passes cannot run inside this process): HBM bytes per launch and the
             # issue-side counters, each labelled with the profile it came from so that a stale file cannot pass as live.
             pmc, issue = {}, {}
