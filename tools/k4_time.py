@@ -1,4 +1,5 @@
-"""Time only the bf16 MLP backward kernel at the BASELINE size (HBR_LIB selects the build under test)."""
+"""Time only the bf16 MLP backward kernel at the BASELINE size (HBR_LIB selects the build under test).
+K4_RENDER=1: the one-launch MLP forward + compositing + loss + backward (hbr_mlp_render_bwd) instead."""
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
 import torch, ref_cpu
@@ -15,6 +16,11 @@ amax = torch.zeros(16, device=dev)
 P = torch.cat([v.reshape(-1) for v in ref_cpu.mlp_init(0).values()]).to(dev)
 dout = torch.randn((N, 4), device=dev)
 dP = torch.zeros_like(P)
+if os.environ.get("K4_RENDER") == "1":  # same harness, the render variant: d out is formed in the kernel
+    t = ref_cpu.strat_jitter_to_t(2.0, 6.0, S, torch.rand(S)).to(dev)
+    dn_d, gt_d = dn.reshape(-1).to(dev), gt.to(dev)
+    _bwd = ops.mlp_bwd
+    ops.mlp_bwd = lambda feat, lay, pe, S_, P, prec, dout, dP, absmax_out=None: ops.mlp_render_bwd(feat, pe, P, prec, t, dn_d, gt_d, dP, absmax_out=absmax_out)[1]
 for _ in range(3):
     ops.mlp_bwd(feat, PLANAR, pe, S, P, BF16, dout, dP, absmax_out=amax)
 torch.cuda.synchronize()
