@@ -1376,25 +1376,31 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const char* __restri
       if (rvalid) {
         const float dn = ra.dir_norm ? ra.dir_norm[ray] : 1.f;
         const float4* row = rays + (wv - wr) * 32;  // the ray's S samples
-        RayComposite<2> rc;
+        auto composite = [&](auto nch_tag) {  // one 64-lane chunk for S <= 64 (train_hash2.py:29's default), two for S = 128
+          constexpr int NCH = decltype(nch_tag)::value;
+          RayComposite<NCH> rc;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const uint32_t sidx = 64u * c + (uint32_t)lane;
-          rc.v[c] = sidx < ra.S ? row[sidx] : make_float4(0.f, 0.f, 0.f, 0.f);
-          rc.dl[c] = __fmul_rn(tdl[c], dn);  // helper.py:67,71 (0 for the last sample and beyond)
-        }
-        rc.run((int)ra.S, lane, ra.gt[ray * 3 + 0], ra.gt[ray * 3 + 1], ra.gt[ray * 3 + 2], ra.k);
-        if (wr == 0) {
-          se_acc += rc.se;
-          if (ra.Cr && lane == 0) { ra.Cr[ray * 3 + 0] = rc.c0; ra.Cr[ray * 3 + 1] = rc.c1; ra.Cr[ray * 3 + 2] = rc.c2; }
-        }
-        // my samples are 32 wr + (lane & 31): chunk wr >> 1, lanes 32 (wr & 1) + ...
-        float4 mine = (wr & 2) ? rc.d[1] : rc.d[0];
-        if (wr & 1) {
-          const int src = (lane & 31) + 32;
-          mine = make_float4(__shfl(mine.x, src), __shfl(mine.y, src), __shfl(mine.z, src), __shfl(mine.w, src));
-        }
-        if (h == 0 && valid) dO = mine;
+          for (int c = 0; c < NCH; ++c) {
+            const uint32_t sidx = 64u * c + (uint32_t)lane;
+            rc.v[c] = sidx < ra.S ? row[sidx] : make_float4(0.f, 0.f, 0.f, 0.f);
+            rc.dl[c] = __fmul_rn(tdl[c], dn);  // helper.py:67,71 (0 for the last sample and beyond)
+          }
+          rc.run((int)ra.S, lane, ra.gt[ray * 3 + 0], ra.gt[ray * 3 + 1], ra.gt[ray * 3 + 2], ra.k);
+          if (wr == 0) {
+            se_acc += rc.se;
+            if (ra.Cr && lane == 0) { ra.Cr[ray * 3 + 0] = rc.c0; ra.Cr[ray * 3 + 1] = rc.c1; ra.Cr[ray * 3 + 2] = rc.c2; }
+          }
+          // my samples are 32 wr + (lane & 31): chunk wr >> 1, lanes 32 (wr & 1) + ...
+          float4 mine = rc.d[0];
+          if constexpr (NCH == 2) mine = (wr & 2) ? rc.d[1] : rc.d[0];
+          if (wr & 1) {
+            const int src = (lane & 31) + 32;
+            mine = make_float4(__shfl(mine.x, src), __shfl(mine.y, src), __shfl(mine.z, src), __shfl(mine.w, src));
+          }
+          if (h == 0 && valid) dO = mine;
+        };
+        if (ra.S > 64u) composite(std::integral_constant<int, 2>{});
+        else composite(std::integral_constant<int, 1>{});
       }
     }
 

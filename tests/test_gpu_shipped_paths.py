@@ -624,7 +624,7 @@ def test_k2_other_level_counts_vs_oracle_and_absmax_handoff(ops, L):
         ops.mlp_fwd(torch.zeros((L, 64, 2), device=DEV), PLANAR, torch.zeros((1, 24), device=DEV), 64, mlp.flat_params()[0], 0)
 
 
-@pytest.mark.parametrize("log2T", [17, 19])
+@pytest.mark.parametrize("log2T", [17, 18, 19])  # 8 slices: unmasked sweep; 16 (the threshold) and 32: masked
 def test_k2_large_tables_vs_oracle(ops, log2T):
     """train_hash2.py:36 --hash_size above the README's 16 (19 is the Instant-NGP default the flag reaches): the LDS
     kernels on 131 072 points against the oracle, bit-identical re-run, and the two flushes / the global-atomics kernel
