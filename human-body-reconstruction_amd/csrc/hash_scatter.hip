@@ -24,6 +24,7 @@
 //     level, each keeping the corners that fall into its slice.  The x term of the hash is the cell coordinate
 //     itself, so the two x-neighbours of a (y, z) pair are always in the slice together: four tests, not eight.
 //   Chunk partials leave the workgroups as plain stores and are summed in a fixed order (slab_reduce_kernel).
+#include <cstdlib>
 #include <mutex>
 #include <type_traits>
 
@@ -50,7 +51,7 @@ constexpr int64_t kDenseMaxT = 1LL << 22;      // the per-level int64 row table 
 // slice; a slice owner then loads its chunk's coordinates as before but VISITS only the flagged points, compacted
 // through a per-wave LDS ring - 4 (1 - (1 - 1/spl)^4) / spl of the points instead of all of them (12 % at spl = 32).
 // The unmasked form is linear in T: 0.52 / 0.94 / 1.65 / 4.24 / 7.44 ms at T = 2^16 .. 2^20 (profiles/r04_k2_vs_T.txt);
-// masked: 1.31 / 1.90 / 3.28 ms at 2^18 .. 2^20.  What is left is bandwidth, not arithmetic: every slice owner still
+// masked: 1.20 / 1.87 / 3.08 ms at 2^18 .. 2^20.  What is left is bandwidth, not arithmetic: every slice owner still
 // STREAMS its chunk's coordinates and dy (16 B per point) to pick its 12 % - 64 owners per level at 2^19 = 33 GB of
 // L2 -> L1 traffic per call; a 128-byte line holds ten points, so gathering only the flagged ones would fetch 3/4 of
 // the lines anyway, and routing (x, y, z, dy) payloads to the owners through memory is 6 GB of HBM traffic.
@@ -599,48 +600,53 @@ __device__ __forceinline__ void hashed_slice_body(const uint32_t b, unsigned lon
       head += count;
       visit(nonneg_tag, e.x, e.y, e.z, e.w);
     };
-    for (uint32_t s = s_begin + wv; s < s_end; s += kLdsBwdThreads / 64) {
-      const unsigned long long mine = mrow[(size_t)s * kSeg + (lane & (kSeg - 1))];  // lane m holds step m's mask
-      const uint32_t m_lo = (uint32_t)mine, m_hi = (uint32_t)(mine >> 32);
+    // (the wave index as a scalar: the stripe index, and with it the address of the stripe's 16 mask words, is then
+    // wave-uniform by construction - the words arrive by scalar loads, no v_readlane per step)
+    const uint32_t wv_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)wv);
+    for (uint32_t s = s_begin + wv_s; s < s_end; s += kLdsBwdThreads / 64) {
+      const unsigned long long* mstripe = mrow + (size_t)s * kSeg;  // step m's mask: mstripe[m]
       const float* q = xnorm + ((size_t)s * 1024u + lane) * 3;
       const uint32_t n0 = s * 1024u + lane * kSeg;
-      const bool vec = vec_ok && s * 1024u + 1024u <= N;  // uniform
-      SegDy<DTYPE> seg;
-      if (vec) seg.load(dy, l, N, n0);
-      else {
+      // one stripe with the dy source fixed at compile time (VEC: the lane's 16 values from one vector load; else a
+      // load per flagged point): the choice is per stripe, and inside the 16-step loop it cost six instructions a step
+      auto stripe = [&](auto vec_tag) {
+        constexpr bool VEC = decltype(vec_tag)::value;
+        SegDy<DTYPE> seg;
+        if constexpr (VEC) seg.load(dy, l, N, n0);
 #pragma unroll
-        for (int k = 0; k < SegDy<DTYPE>::kVecs; ++k) seg.v[k] = make_uint4(0u, 0u, 0u, 0u);
-      }
+        for (int g8 = 0; g8 < kSeg; g8 += 8) {
+          float cx[8], cy[8], cz[8];
 #pragma unroll
-      for (int g8 = 0; g8 < kSeg; g8 += 8) {
-        float cx[8], cy[8], cz[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {  // eight steps' coordinates in flight
-          const float* qq = q + (g8 + k) * 64 * 3;
-          cx[k] = qq[0]; cy[k] = qq[1]; cz[k] = qq[2];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int m = g8 + k;
-          const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)m_lo, m), hi = (uint32_t)__builtin_amdgcn_readlane((int)m_hi, m);
-          if ((lo | hi) == 0u) continue;  // uniform
-          if (((lo & bit_lo) | (hi & bit_hi)) != 0u) {
-            float dv;
-            if (vec) {
-              dv = seg.pick(m, f, psel);
-            } else {
-              const uint2 raw = load_feat_raw<LAYOUT, DTYPE>(dy, n0 + m, l, N, dy_stride);  // a flagged point is < N
-              float d0, d1;
-              decode_feat<DTYPE>(raw, d0, d1);
-              dv = f ? d1 : d0;
-            }
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
-            ring[(tail + rank) & (kRing - 1)] = make_float4(cx[k], cy[k], cz[k], dv);
+          for (int k = 0; k < 8; ++k) {  // eight steps' coordinates in flight
+            const float* qq = q + (g8 + k) * 64 * 3;
+            cx[k] = qq[0]; cy[k] = qq[1]; cz[k] = qq[2];
           }
-          tail += (uint32_t)__builtin_popcount(lo) + (uint32_t)__builtin_popcount(hi);
-          if (tail - head >= 64u) pop(64u);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int m = g8 + k;
+            const unsigned long long mask = mstripe[m];
+            const uint32_t lo = (uint32_t)mask, hi = (uint32_t)(mask >> 32);
+            if ((lo | hi) == 0u) continue;  // uniform
+            if (((lo & bit_lo) | (hi & bit_hi)) != 0u) {
+              float dv;
+              if constexpr (VEC) {
+                dv = seg.pick(m, f, psel);
+              } else {
+                const uint2 raw = load_feat_raw<LAYOUT, DTYPE>(dy, n0 + m, l, N, dy_stride);  // a flagged point is < N
+                float d0, d1;
+                decode_feat<DTYPE>(raw, d0, d1);
+                dv = f ? d1 : d0;
+              }
+              const uint32_t rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+              ring[(tail + rank) & (kRing - 1)] = make_float4(cx[k], cy[k], cz[k], dv);
+            }
+            tail += (uint32_t)__builtin_popcount(lo) + (uint32_t)__builtin_popcount(hi);
+            if (tail - head >= 64u) pop(64u);
+          }
         }
-      }
+      };
+      if (vec_ok && s * 1024u + 1024u <= N) stripe(std::true_type{});  // uniform
+      else stripe(std::false_type{});
     }
     if (tail != head) pop(tail - head);
   };
@@ -905,13 +911,16 @@ static int lds_slices(int64_t T) { return (int)((T + kSliceRows - 1) / kSliceRow
 // the masked form of the hashed branch (slice_mask_kernel + ring visits) pays from sixteen slices per level
 static bool lds_masked(int spl) { return spl >= kMaskMinSlices && spl <= kMaskMaxSlices; }
 // Chunks of the masked form: every (level, slice, feature) owner scans the masks of ALL its chunk's stripes whatever it
-// visits, and each chunk costs a 64 KiB slab per owner - so as few chunks as still give ~1500 workgroups (six rounds of
-// the 256 CUs at 16 levels): 3 at 16 slices, 2 at 32, 1 from 64.  Depends on N and T only, like lds_chunks.  (No
-// limit on the points per workgroup is needed: the fixed-point scale is derived from N, so no sum over any subset of a
-// launch's contributions can overflow.)
+// visits, and each chunk costs a 64 KiB slab per owner - few chunks.  Measured (HBR_K2_MASK_CHUNKS, gpurun_out/k2_mask_chunks.txt;
+// K2 span in ms at 2^18 / 2^19 / 2^20): 1 chunk 1.51 / 1.89 / 3.27, 2 chunks 1.21 / 1.91 / 3.14, 3 chunks 1.32 / 2.25 / 5.05 (an odd
+// count puts the chunks of one slice on different XCDs from call to call), 4 chunks 1.24 / 1.86 / 3.24, 8 chunks 1.23 / 1.95 / 3.38:
+// two.  Depends on N and T only, like lds_chunks.  (No limit on the points per workgroup is needed: the fixed-point
+// scale is derived from N, so no sum over any subset of a launch's contributions can overflow.)
 static int lds_chunks_masked(int64_t N, int spl) {
-  constexpr int kTargetBlocks = 1536, kRefLevels = 16;
-  int chunks = (kTargetBlocks + kRefLevels * spl * 2 - 1) / (kRefLevels * spl * 2);
+  int chunks = 2;
+  (void)spl;
+  static const char* force = getenv("HBR_K2_MASK_CHUNKS");  // tuning runs only (tools/k2_vs_T.sh)
+  if (force && atoi(force) > 0) chunks = atoi(force);
   const int max_chunks = (int)((N + kLdsBwdThreads - 1) / kLdsBwdThreads);
   if (chunks > max_chunks) chunks = max_chunks;
   return chunks < 1 ? 1 : chunks;
