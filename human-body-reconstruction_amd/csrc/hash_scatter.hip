@@ -2,7 +2,7 @@
 // aten::embedding_dense_backward + the mul/sum backward), gfx950.  Entry point: hbr_hash_encode_bwd.
 //
 // algo 1 (hash_encode.hip): one global float atomic per corner-feature.  ~55 ms at the README batch - memory-side
-//   atomics on scattered rows run at ~10 G/s - kept for small N and as a cross-check.
+//   atomics on scattered rows run at ~10 G/s - kept for fewer than 4096 points and as a cross-check.
 // algo 2 (this file): accumulate in LDS, in 64-bit FIXED POINT.
 //   Measured on MI355X (tools/lds_atomic_bench2.hip), cycles per wave-instruction at all / a quarter of the lanes:
 //     ds_add_f32 193 / 48 (3 cycles per active lane whatever the FP mode; ds_pk_add_bf16/f16 and the rtn form the same),
@@ -43,6 +43,11 @@ constexpr int kChunkPointsLog2Max = 19;        // a hashed-slice workgroup sweep
 constexpr double kRoundMagic = 6755399441055744.0;  // 1.5 * 2^52: x + magic has round-to-nearest(x) in its low mantissa bits
 constexpr uint32_t kRoundMagicHi = 0x43380000u;      // its high word (the low word is 0)
 constexpr int kAbsBlocks = 512;                // partial maxima per level (absmax kernels' grid.x)
+// `algo 0` (auto) takes the LDS kernels from this many points.  Until round 4 it was 65 536 ("enough points to amortise the
+// 128 KiB flush per workgroup") - never measured: global float atomics cost 24 ns per point whatever N, the LDS kernels
+// ~0.06 ms up to 16 Ki points and 0.08 / 0.12 ms at 32 / 64 Ki, so at 8 / 32 Ki points auto ran 3.5x / 9x slower than it had to
+// (tools/k2_small_n.py: 0.204 / 0.764 ms against 0.058 / 0.083; the two meet at 2048 points).
+constexpr uint32_t kLdsAutoMinPoints = 4096;
 constexpr int kDenseLevels = 6;                // dense levels are a prefix of the levels; at most this many
 constexpr int kDenseCap = 10000;               // vertices of a dense table with both features (160 000 B of LDS)
 constexpr int64_t kDenseMaxT = 1LL << 22;      // the per-level int64 row table of the dense path is T*16 B (cleared and re-read per call)
@@ -1062,11 +1067,11 @@ static bool token_matches(const CoordToken& tk) {
 using namespace hbr;
 
 extern "C" int64_t hbr_hash_bwd_workspace_bytes(int64_t N, int L, int64_t T, int, int algo) {
-  if (algo == 1 || (algo == 0 && N < 65536) || !lds_shape_ok(N, L, T)) return 0;
+  if (algo == 1 || (algo == 0 && N < (int64_t)kLdsAutoMinPoints) || !lds_shape_ok(N, L, T)) return 0;
   return workspace(N, L, T).total;  // (the coordinate part depends on N only, so it is shared by calls over level sub-ranges)
 }
 extern "C" int64_t hbr_hash_bwd_workspace_bytes_min(int64_t N, int L, int64_t T, int, int algo) {
-  if (algo == 1 || (algo == 0 && N < 65536) || !lds_shape_ok(N, L, T)) return 0;
+  if (algo == 1 || (algo == 0 && N < (int64_t)kLdsAutoMinPoints) || !lds_shape_ok(N, L, T)) return 0;
   return workspace(N, L, T).min_total;
 }
 
@@ -1103,7 +1108,7 @@ extern "C" int hbr_hash_encode_bwd(const float* x, const float* rays_o, const fl
     if (!shape_ok) return HBR_EUNSUPPORTED;
     if (!ws_ok) return HBR_EWORKSPACE;
   }
-  if (algo == 0) algo = (N >= 65536u && ws_ok) ? 2 : 1;
+  if (algo == 0) algo = (N >= kLdsAutoMinPoints && ws_ok) ? 2 : 1;
   if (overwrite && (algo == 1 || ws_bytes < w.total)) return HBR_EUNSUPPORTED;  // float atomics add to what is there
   if (algo == 1) {
     rc = launch_hash_bwd_atomic(st, ps, N, dy, layout, dy_stride, dy_dtype, g, dtables);

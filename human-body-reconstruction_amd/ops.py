@@ -170,7 +170,7 @@ def hash_encode_bwd(geom: HashGeom, dy: torch.Tensor, dtables: torch.Tensor, x: 
                     layout: int = ROWS, algo: int = 0, dy_absmax: Optional[torch.Tensor] = None, deterministic: bool = True,
                     overwrite: bool = False):
     """Accumulates into dtables [L,T,F] fp32 - or, with `overwrite`, leaves exactly this call's gradient there whatever
-    the buffer held (written by the kernels where each row has one writer, else zeroed here first).  algo 0 = auto (LDS fixed-point kernels from 65536 points), 1 = global
+    the buffer held (written by the kernels where each row has one writer, else zeroed here first).  algo 0 = auto (LDS fixed-point kernels from 4096 points), 1 = global
     float atomics, 2 = LDS kernels, 3 = LDS kernels re-using the coordinates the previous call (same points, same
     stream) left in the workspace.  `deterministic` (algo 2): reduce the chunk partials in a fixed order (full
     workspace) instead of with float atomics.  `dy_absmax` [L] fp32 on the device: per-level max |dy| if the caller

@@ -221,8 +221,9 @@ class HashNeRFTrainer:
                 # the second launch re-uses the first one's coordinates (algo 2 then 3; the first is the larger, so its
                 # workspace fits both) - where the LDS kernels can run at all: for a shape they refuse (T > 2^28:
                 # workspace size 0) both take the caller's algo, so a model that trains on one GPU does not raise on N
-                lds = (self.scatter_algo in (0, 2) and R * S >= 65536
-                       and _lib.lib().hbr_hash_bwd_workspace_bytes(R * S, g.L - half, g.T, g.F, 2) > 0)
+                # (asking with the caller's algo: 0 = auto answers 0 bytes below the size from which it picks the LDS kernels)
+                lds = (self.scatter_algo in (0, 2)
+                       and _lib.lib().hbr_hash_bwd_workspace_bytes(R * S, g.L - half, g.T, g.F, self.scatter_algo) > 0)
                 # pieces: [upper levels | MLP block] - contiguous in the flat buffer, final once K4 and the first launch
                 # are done - then the lower levels
                 for k, (lo, hi, piece) in enumerate(((half, g.L, self.grad[cut:]), (0, half, self.grad[:cut]))):

@@ -155,7 +155,7 @@ HBR_API int hbr_hash_encode_fwd(const float* x, const float* rays_o, const float
  *                mu, sigma) and on which stream; algo 3 returns HBR_EINVAL unless this call names exactly those - e.g.
  *                when another caller ran an algo-2 backward on the same workspace in between.  (What it cannot see: a
  *                kernel of another stream overwriting `ws`; a workspace belongs to one stream.)
- *            0 = auto: 2 when N >= 65536, T <= 2^28 and the workspace suffices, else 1
+ *            0 = auto: 2 when N >= 4096 (where the two cost the same; 65536 until round 4), T <= 2^28 and the workspace suffices, else 1
  *   ws       16-byte-aligned scratch of hbr_hash_bwd_workspace_bytes() bytes (normalised coordinates, per-level
  *            maxima, per-chunk partial tables); contents are dead after the call
  *   errors   algo 2 without enough workspace -> HBR_EWORKSPACE; algo 2 with T > 2^28 -> HBR_EUNSUPPORTED
