@@ -96,6 +96,11 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise HbrError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU/eager fallback for this path)")
+        # torch first: it ships its own HIP runtime (torch/lib/libamdhip64.so).  Loaded before the library, that runtime
+        # also satisfies the library's libamdhip64.so.7 dependency - ONE runtime in the process.  The other way round
+        # (library first: /opt/rocm's runtime, then torch's next to it) the process holds two, and whichever initialises
+        # second does not see the device (seen as hbr_device_ok() == 0 when build() and smoke() shared a process).
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the .so does not export it
