@@ -342,6 +342,9 @@ def mlp_render_bwd(feat: torch.Tensor, viewdirs_enc: torch.Tensor, params: torch
         return None
     R = N // S
     gt, t = _f32c(gt), _f32c(t)
+    viewdirs_enc = _f32c(viewdirs_enc)
+    if tuple(viewdirs_enc.shape) != (R, 24) or tuple(gt.shape) != (R, 3):
+        raise HbrError(f"mlp_render_bwd: viewdirs_enc must be [{R}, 24] and gt [{R}, 3] for {R} rays x {S} samples")
     if dir_norm is not None:
         dir_norm = _f32c(dir_norm).reshape(-1)
         if dir_norm.numel() != R:
