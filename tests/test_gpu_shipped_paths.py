@@ -413,6 +413,17 @@ for name, fdt, prec in (("bf16", torch.bfloat16, BF16), ("f32", torch.float32, F
     df = ops.mlp_bwd(f, PLANAR, pe, S, P, prec, dout, dP, absmax_out=amax)
     res[name + "_out"] = out.cpu().numpy(); res[name + "_dP"] = dP.cpu().numpy()
     res[name + "_df"] = df.float().cpu().numpy(); res[name + "_amax"] = amax.cpu().numpy()
+# the one-launch render + backward (round 4) through the same two addressing paths: 64 rays x 32 samples
+R2, S2 = 67, 32
+g2 = torch.Generator().manual_seed(12)
+feat2 = (torch.randn((16, R2 * S2, 2), generator=g2) * 0.3).bfloat16().to(dev)
+_, d2, _, gt2 = ref_cpu.synthetic_rays(R2, seed=4)
+pe2 = ops.dir_encode(d2.to(dev), 4)
+t2 = ref_cpu.strat_jitter_to_t(2.0, 6.0, S2, torch.rand(S2, generator=g2)).to(dev)
+dP2 = torch.zeros_like(P); amax2 = torch.zeros(16, device=dev)
+loss2, df2, Cr2 = ops.mlp_render_bwd(feat2, pe2, P, BF16, t2, None, gt2.to(dev), dP2, absmax_out=amax2, want_Cr=True)
+res["render_loss"] = np.array(float(loss2)); res["render_dP"] = dP2.cpu().numpy(); res["render_df"] = df2.float().cpu().numpy()
+res["render_Cr"] = Cr2.cpu().numpy(); res["render_amax"] = amax2.cpu().numpy()
 np.savez(sys.argv[2], **res)
 """
 
@@ -431,10 +442,10 @@ def test_mlp_64bit_addressing_path_equals_32bit_path(tmp_path):
         r = subprocess.run([sys.executable, "-c", _ADDR_SCRIPT, ROOT, path], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[tag] = np.load(path)
-    assert set(outs["a32"].files) == set(outs["a64"].files) and len(outs["a32"].files) == 8
+    assert set(outs["a32"].files) == set(outs["a64"].files) and len(outs["a32"].files) == 13
     for k in outs["a32"].files:
         assert np.array_equal(outs["a32"][k], outs["a64"][k]), k
-    assert np.abs(outs["a32"]["bf16_df"]).max() > 0 and np.abs(outs["a32"]["f32_dP"]).max() > 0
+    assert np.abs(outs["a32"]["bf16_df"]).max() > 0 and np.abs(outs["a32"]["f32_dP"]).max() > 0 and np.abs(outs["a32"]["render_df"]).max() > 0
 
 
 @pytest.mark.parametrize("precision", [1, 0])
