@@ -16,11 +16,13 @@ constexpr int kXcds = 8;
 // launch waits for group 0.  Odd point tiles therefore take the MIRRORED pair ({7-k, 8+k} on the XCD that has {k, 15-k}
 // for the even ones): every XCD then carries (187 + 63) / 2 ... (142 + 122) / 2 = 125-132 us, and its L2 holds four
 // tables (2 of its 4 MiB) instead of two.
-__device__ __forceinline__ int group_level(int group, int j, uint32_t tile) {
+// `mirror` (run time, round 4): off for tables so large that an XCD's L2 cannot hold the four level tables the mirrored map
+// gives it (hbr_hash_encode_fwd decides; the global-atomics backward always mirrors).
+__device__ __forceinline__ int group_level(int group, int j, uint32_t tile, bool mirror = true) {
 #ifndef HBR_K1_MIRROR
 #define HBR_K1_MIRROR 1
 #endif
-  const bool mirrored = HBR_K1_MIRROR == 2 ? tile >= (gridDim.x / kXcds + 1) / 2 : (HBR_K1_MIRROR == 1 && (tile & 1u));
+  const bool mirrored = mirror && (HBR_K1_MIRROR == 2 ? tile >= (gridDim.x / kXcds + 1) / 2 : (HBR_K1_MIRROR == 1 && (tile & 1u)));
   const int g = mirrored ? 7 - group : group;
   return 8 * j + ((j & 1) ? 7 - g : g);
 }

@@ -9,6 +9,8 @@
 //
 // Backward, algo 1 (kept for small N and as a cross-check): one global float atomic per corner-feature.  The LDS
 // algorithms that the trainer uses live in hash_scatter.hip.
+#include <cstdlib>
+
 #include "hash_common.h"
 
 namespace hbr {
@@ -19,7 +21,7 @@ namespace hbr {
 template <bool POW2, int LAYOUT, int DTYPE>
 __global__ __launch_bounds__(kFwdThreads) void hash_fwd_kernel(PointSrc ps, uint32_t N, const float* __restrict__ tables,
                                                                HashGeom g, void* __restrict__ y, int64_t y_stride,
-                                                               int levels_per_group) {
+                                                               int j_begin, int j_end, int mirror) {
   const int group = blockIdx.x % kXcds;
   const uint32_t tile = blockIdx.x / kXcds;
   const uint32_t n = tile * kFwdThreads + threadIdx.x;
@@ -32,8 +34,8 @@ __global__ __launch_bounds__(kFwdThreads) void hash_fwd_kernel(PointSrc ps, uint
   if (group != HBR_K1_ONLY_GROUP) return;
 #endif
 
-  for (int j = 0; j < levels_per_group; ++j) {
-    const int l = group_level(group, j, tile);
+  for (int j = j_begin; j < j_end; ++j) {
+    const int l = group_level(group, j, tile, mirror != 0);
     if (l >= g.L) continue;
 #ifdef HBR_K1_ONLY_LEVEL  // timing-only variant: one level's work alone
     if (l != HBR_K1_ONLY_LEVEL) continue;
@@ -99,13 +101,22 @@ __global__ __launch_bounds__(kFwdThreads) void hash_bwd_atomic_kernel(PointSrc p
   }
 }
 
+// The mirrored level map (hash_common.h) balances the XCDs but gives each of them FOUR level tables; it pays while those fit
+// the XCD's 4 MiB L2 (T <= 2^17 at L = 16).  Beyond, the plain map (two tables per XCD) is faster - measured (hash_fwd, ms;
+// gpurun_out/k1_split.txt) at T = 2^16 .. 2^20: mirrored 0.250 / 0.256 / 0.369 / 0.465 / 0.567, plain 0.281 / 0.286 / 0.292 /
+// 0.397 / 0.552.  (Also measured, and worse everywhere: one launch per level index so that an XCD works on one level at a
+// time - 0.33 - 0.65 ms: the points are regenerated per launch and each launch has half the work in flight.)
+// HBR_K1_MIRROR_RT=0/1: tuning override.
 template <bool POW2, int LAYOUT>
 static int launch_fwd_dtype(int dtype, dim3 grid, hipStream_t st, PointSrc ps, uint32_t N, const float* tables,
                             const HashGeom& g, void* y, int64_t stride, int lpg) {
+  static const char* e_mirror = getenv("HBR_K1_MIRROR_RT");
+  int mirror = g.T * 8 * lpg * 2 <= (4LL << 20) ? 1 : 0;
+  if (e_mirror) mirror = atoi(e_mirror) != 0;
   if (dtype == HBR_F32)
-    hipLaunchKernelGGL((hash_fwd_kernel<POW2, LAYOUT, HBR_F32>), grid, dim3(kFwdThreads), 0, st, ps, N, tables, g, y, stride, lpg);
+    hipLaunchKernelGGL((hash_fwd_kernel<POW2, LAYOUT, HBR_F32>), grid, dim3(kFwdThreads), 0, st, ps, N, tables, g, y, stride, 0, lpg, mirror);
   else
-    hipLaunchKernelGGL((hash_fwd_kernel<POW2, LAYOUT, HBR_BF16>), grid, dim3(kFwdThreads), 0, st, ps, N, tables, g, y, stride, lpg);
+    hipLaunchKernelGGL((hash_fwd_kernel<POW2, LAYOUT, HBR_BF16>), grid, dim3(kFwdThreads), 0, st, ps, N, tables, g, y, stride, 0, lpg, mirror);
   return HBR_OK;
 }
 
