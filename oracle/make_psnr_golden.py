@@ -69,7 +69,8 @@ def scene():
     return mn, sig, batches, test
 
 
-def run_seed(ref_dir: str, seed: int, steps: int, eval_every: int, out: str, threads: int, perturb_ulps: int = 0, save_final: str = ""):
+def run_seed(ref_dir: str, seed: int, steps: int, eval_every: int, out: str, threads: int, perturb_ulps: int = 0, save_final: str = "",
+             autocast_bf16: bool = False):
     import make_golden as MG
     import ref_cpu
     torch.set_num_threads(threads)
@@ -94,24 +95,27 @@ def run_seed(ref_dir: str, seed: int, steps: int, eval_every: int, out: str, thr
     for k in range(steps):
         o, d, dn, gt = batches[k % NB]
         t = ref_cpu.strat_jitter_to_t(NEAR, FAR, S, torch.from_numpy(u[k]))
-        Cr, Cf, _ = MG.quiet(vr.vol_render, nerf, d, o, num_samples=S, t=t, update_mask=False, dir_norm=dn, hierarchical=False)
-        loss = crit(Cr, gt) + crit(Cf, gt)
+        # --autocast-bf16: the reference's loop runs its forward + loss under autocast (train_hash2.py:218-221; fp16 on its CUDA
+        # device); the CPU equivalent is bf16 - the reference's OWN modules at reduced precision, for the bf16 rows of the study
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast_bf16):
+            Cr, Cf, _ = MG.quiet(vr.vol_render, nerf, d, o, num_samples=S, t=t, update_mask=False, dir_norm=dn, hierarchical=False)
+            loss = crit(Cr, gt) + crit(Cf, gt)
         loss.backward()
         opt_e.step(); opt_m.step()
         sch_e.step(); sch_m.step()
         opt_m.zero_grad(set_to_none=True); opt_e.zero_grad(set_to_none=True)
         losses[k] = float(loss)
         if (k + 1) % eval_every == 0 or k + 1 == steps:
-            with torch.no_grad():
+            with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast_bf16):
                 C, _, _ = MG.quiet(vr.vol_render, nerf, test[1], test[0], num_samples=S, t=t_eval, update_mask=False,
                                    dir_norm=test[2], hierarchical=False)
-                p = float(ref.helper.calc_psnr(C, test[3]))
+                p = float(ref.helper.calc_psnr(C.float(), test[3]))
             ev_steps.append(k + 1); ev_psnr.append(p)
             print(f"seed {seed} step {k + 1:5d} loss {losses[k]:.5f} held-out PSNR {p:.3f} dB ({time.time() - t0:.0f}s)", flush=True)
             np.savez(out, seed=seed, steps=steps, eval_steps=np.array(ev_steps), psnr=np.array(ev_psnr, dtype=np.float64),
                      loss=losses[:k + 1], input_checksum=checksum(tables0, u, *[v.numpy() for v in params0.values()]),
                      scene_checksum=checksum(*[a.numpy() for b in batches[:2] for a in b], *[a.numpy() for a in test]),
-                     perturb_ulps=perturb_ulps)
+                     perturb_ulps=perturb_ulps, autocast_bf16=int(autocast_bf16))
     if save_final:  # the trained parameters + the reference's own render of the held-out rays with them
         with torch.no_grad():
             C, _, _ = MG.quiet(vr.vol_render, nerf, test[1], test[0], num_samples=S, t=t_eval, update_mask=False, dir_norm=test[2], hierarchical=False)
@@ -186,6 +190,7 @@ if __name__ == "__main__":
     ap.add_argument("--out", default="/tmp/psnr_seed.npz")
     ap.add_argument("--perturb-ulps", type=int, default=0)
     ap.add_argument("--save-final", default="")
+    ap.add_argument("--autocast-bf16", action="store_true", help="run the reference's forward + loss under torch.autocast(cpu, bfloat16)")
     ap.add_argument("--merge", nargs="+")
     ap.add_argument("--merge-ulp", nargs="*", default=[], help="the perturbed re-runs (any --perturb-ulps), all seeds of --merge")
     ap.add_argument("--merge-degenerate", nargs="*", default=[], help="runs of seeds the reference itself does not train from")
@@ -193,4 +198,4 @@ if __name__ == "__main__":
     if a.merge:
         merge(a.merge, a.merge_ulp, a.merge_degenerate)
     else:
-        run_seed(a.ref, a.seed, a.steps, a.eval_every, a.out, a.threads, a.perturb_ulps, a.save_final)
+        run_seed(a.ref, a.seed, a.steps, a.eval_every, a.out, a.threads, a.perturb_ulps, a.save_final, a.autocast_bf16)

@@ -46,5 +46,7 @@ for cfg, v in cfgs.items():
     se_j = np.sqrt(self_delta.var(ddof=1) / self_delta.size + hd.var(ddof=1) / hd.size)
     print(f"{cfg:24s} " + " ".join(f"{x:+7.2f}" for x in d) + f"  {D:+6.2f}   {se:5.2f}    {zn:+5.1f}    {hw:.3f} ({hw / rw:.2f}x)"
           f"                 mean delta vs unperturbed {hd.mean():+.2f}; self {self_delta.mean():+.2f} +- {2 * se_j:.2f}")
-    if "5" in v:
-        print(f"{'':24s} seed 5 (degenerate): HIP " + " ".join(f"{c[-1]:.2f}" for c in v["5"].values()) + " dB")
+    for ds in ([int(x) for x in g["degenerate_seeds"]] if "degenerate_seeds" in g.files else []):
+        if str(ds) in v:
+            print(f"{'':24s} seed {ds} (degenerate): HIP " + " ".join(f"{c[-1]:.2f}" for c in v[str(ds)].values()) + " dB")
+    print(f"{'':24s} per-seed deltas: sd {d.std(ddof=1):.2f} dB; expected from within-seed noise alone {np.sqrt((rw ** 2 + hw ** 2) / hip.shape[1]):.2f}")
