@@ -24,6 +24,7 @@ Usage (one process per seed, ~50 min each on one thread, then merge):
     ... --seed 1 --perturb-ulps 2 / --perturb-ulps -1 ...                                          (round 4: two more per seed)
     python oracle/make_psnr_golden.py --merge /tmp/psnr/s*.npz --merge-ulp /tmp/psnr_p/s?.npz /tmp/psnr4/s?_u2.npz /tmp/psnr4/s?_u-1.npz \
                                       --merge-degenerate /tmp/psnr4/s5_u0.npz                      -> tests/golden/g15_converged_psnr.npz
+    ... --seed 1 --autocast-bf16 [--perturb-ulps 1] ...; --merge ... --merge-autocast /tmp/psnr6/s*_ac*.npz   (round 4, late: the reference under bf16)
     cp /tmp/psnr_p/final_s1.npz tests/golden/g15b_trained_weights.npz    (the reference's trained weights + its held-out render)
 """
 from __future__ import annotations
@@ -126,12 +127,15 @@ def run_seed(ref_dir: str, seed: int, steps: int, eval_every: int, out: str, thr
         np.savez_compressed(save_final, **fin)
 
 
-def merge(files, ulp_files=(), degenerate_files=()):
+def merge(files, ulp_files=(), degenerate_files=(), autocast_files=()):
     """files: the unperturbed runs (one per seed); ulp_files: re-runs of the same seeds with every initial table entry moved
     by +1 / +2 / -1 ... fp32 ulps (--perturb-ulps: the reference's OWN trajectory noise - same inputs up to 1e-11, same
     code); stored as psnr_self [seed, perturbation, eval] with self_ulps naming the perturbations (psnr_ulp = the +1 row, as
     round 3 stored it).  degenerate_files: runs of seeds from which the reference itself does not train (kept as evidence,
-    excluded from the statistics: degenerate_seeds / psnr_degenerate)."""
+    excluded from the statistics: degenerate_seeds / psnr_degenerate).  autocast_files: runs of the same seeds with the reference's
+    forward + loss under torch.autocast("cpu", bfloat16) (--autocast-bf16; train_hash2.py:218 runs under autocast on its GPU) -
+    the reference's OWN modules at the precision of the shipped bf16 MLP: psnr_bf16 [seed, run, eval], bf16_ulps = their
+    --perturb-ulps."""
     runs = sorted((np.load(f) for f in files), key=lambda z: int(z["seed"]))
     seeds = [int(z["seed"]) for z in runs]
     extra = {}
@@ -154,6 +158,17 @@ def merge(files, ulp_files=(), degenerate_files=()):
         extra["degenerate_seeds"] = np.array([int(z["seed"]) for z in dz])
         extra["psnr_degenerate"] = np.stack([z["psnr"] for z in dz])
         extra["degenerate_input_checksum"] = np.array([float(z["input_checksum"]) for z in dz])
+    if autocast_files:
+        bya = {}
+        for f in autocast_files:
+            z = np.load(f)
+            assert int(z["autocast_bf16"]) == 1 and int(z["eval_steps"][-1]) == int(z["steps"]) and int(z["seed"]) in seeds, f
+            bya.setdefault(int(z["perturb_ulps"]), {})[int(z["seed"])] = z["psnr"]
+        order = sorted(bya, key=lambda u: (abs(u), -u))  # 0, +1, ...
+        for u in order:
+            assert sorted(bya[u]) == seeds, f"autocast runs at {u:+d} ulps: seeds {sorted(bya[u])}, expected {seeds}"
+        extra["bf16_ulps"] = np.array(order)
+        extra["psnr_bf16"] = np.stack([np.stack([bya[u][s] for u in order]) for s in seeds])
     steps = {int(z["steps"]) for z in runs}
     assert len(steps) == 1, "all seeds must share the horizon"
     ev = runs[0]["eval_steps"]
@@ -171,7 +186,9 @@ def merge(files, ulp_files=(), degenerate_files=()):
         tail = p[int(n * 0.8):]
         more = ""
         if "psnr_self" in z.files:
-            more = "; re-runs with the tables moved by " + ", ".join(f"{int(u):+d} ulp: {z['psnr_self'][i][k][-1]:.3f} ({z['psnr_self'][i][k][-1] - p[-1]:+.3f})"
+            if "psnr_bf16" in z.files:
+                more = "; under bf16 autocast " + " ".join(f"{v:.3f}" for v in z["psnr_bf16"][i][:, -1])
+            more += "; re-runs with the tables moved by " + ", ".join(f"{int(u):+d} ulp: {z['psnr_self'][i][k][-1]:.3f} ({z['psnr_self'][i][k][-1] - p[-1]:+.3f})"
                                                                       for k, u in enumerate(z["self_ulps"]))
         print(f"seed {s}: final {p[-1]:.3f} dB; last 20% of the horizon spans {tail.max() - tail.min():.3f} dB{more}")
     if "degenerate_seeds" in z.files:
@@ -194,8 +211,9 @@ if __name__ == "__main__":
     ap.add_argument("--merge", nargs="+")
     ap.add_argument("--merge-ulp", nargs="*", default=[], help="the perturbed re-runs (any --perturb-ulps), all seeds of --merge")
     ap.add_argument("--merge-degenerate", nargs="*", default=[], help="runs of seeds the reference itself does not train from")
+    ap.add_argument("--merge-autocast", nargs="*", default=[], help="--autocast-bf16 runs of the --merge seeds (unperturbed and perturbed)")
     a = ap.parse_args()
     if a.merge:
-        merge(a.merge, a.merge_ulp, a.merge_degenerate)
+        merge(a.merge, a.merge_ulp, a.merge_degenerate, a.merge_autocast)
     else:
         run_seed(a.ref, a.seed, a.steps, a.eval_every, a.out, a.threads, a.perturb_ulps, a.save_final, a.autocast_bf16)

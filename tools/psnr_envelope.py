@@ -50,3 +50,24 @@ for cfg, v in cfgs.items():
         if str(ds) in v:
             print(f"{'':24s} seed {ds} (degenerate): HIP " + " ".join(f"{c[-1]:.2f}" for c in v[str(ds)].values()) + " dB")
     print(f"{'':24s} per-seed deltas: sd {d.std(ddof=1):.2f} dB; expected from within-seed noise alone {np.sqrt((rw ** 2 + hw ** 2) / hip.shape[1]):.2f}")
+
+if "psnr_bf16" in g.files:
+    refb = g["psnr_bf16"][:, :, -1]                     # [seed, run]: the reference's own modules under torch.autocast(cpu, bfloat16)
+    rb = refb.mean(axis=1)
+    print("\nbf16 against bf16: the reference's OWN modules with forward + loss under torch.autocast(cpu, bfloat16) (oracle/make_psnr_golden.py")
+    print("--autocast-bf16; its loop runs under autocast, train_hash2.py:218), runs at " + str([int(u) for u in g["bf16_ulps"]]) + " ulps of the initial tables")
+    for i, s_ in enumerate(seeds):
+        print(f"  seed {s_}: " + " ".join(f"{v:6.2f}" for v in refb[i]) + f"   mean {rb[i]:.2f}   shift against the fp32 seed mean {rb[i] - rm[i]:+.2f}")
+    sh = rb - rm
+    wb = np.sqrt(np.mean(np.var(refb, axis=1, ddof=1))) if refb.shape[1] > 1 else float("nan")
+    print(f"  reference bf16 - reference fp32 (seed means): mean {sh.mean():+.3f}  sd over the seeds {sh.std(ddof=1):.3f}  SE {sh.std(ddof=1) / np.sqrt(len(sh)):.3f};"
+          f" within-seed sd of the bf16 reference runs {wb:.3f}")
+    print(f"{'configuration':24s} " + " ".join(f"seed {s_:<2d}" for s_ in seeds) + "      D     SE_seeds   sd    corr(HIP shift, reference-bf16 shift)   [HIP seed mean - reference bf16 seed mean]")
+    for cfg, v in cfgs.items():
+        try:
+            hip = np.array([[v[str(s_)][str(u)][-1] for u in ulps] for s_ in seeds])
+        except KeyError:
+            continue
+        hm = hip.mean(axis=1)
+        d = hm - rb
+        print(f"{cfg:24s} " + " ".join(f"{x:+7.2f}" for x in d) + f"  {d.mean():+6.2f}   {d.std(ddof=1) / np.sqrt(len(d)):5.2f}    {d.std(ddof=1):.2f}    {np.corrcoef(hm - rm, sh)[0, 1]:+.2f}")
