@@ -159,16 +159,19 @@ def merge(files, ulp_files=(), degenerate_files=(), autocast_files=()):
         extra["psnr_degenerate"] = np.stack([z["psnr"] for z in dz])
         extra["degenerate_input_checksum"] = np.array([float(z["input_checksum"]) for z in dz])
     if autocast_files:
-        bya = {}
+        bya, bya_loss = {}, {}
         for f in autocast_files:
             z = np.load(f)
             assert int(z["autocast_bf16"]) == 1 and int(z["eval_steps"][-1]) == int(z["steps"]) and int(z["seed"]) in seeds, f
             bya.setdefault(int(z["perturb_ulps"]), {})[int(z["seed"])] = z["psnr"]
+            bya_loss.setdefault(int(z["perturb_ulps"]), {})[int(z["seed"])] = z["loss"]
         order = sorted(bya, key=lambda u: (abs(u), -u))  # 0, +1, ...
         for u in order:
             assert sorted(bya[u]) == seeds, f"autocast runs at {u:+d} ulps: seeds {sorted(bya[u])}, expected {seeds}"
         extra["bf16_ulps"] = np.array(order)
         extra["psnr_bf16"] = np.stack([np.stack([bya[u][s] for u in order]) for s in seeds])
+        if 0 in bya_loss:
+            extra["loss_head_bf16"] = np.stack([bya_loss[0][s][:16] for s in seeds])  # first 16 losses of the unperturbed bf16 runs
     steps = {int(z["steps"]) for z in runs}
     assert len(steps) == 1, "all seeds must share the horizon"
     ev = runs[0]["eval_steps"]
